@@ -1,0 +1,234 @@
+/* rt_abi.h -- C ABI of librt_hip.so, the MI355X (gfx950) implementation of the reference's
+ * `ray_colour` hot path.  Plain pointers and sizes only; no C++/torch types cross this boundary.
+ *
+ * The reference (a Rust workspace, paths relative to /root/reference) has NO FFI/plugin interface:
+ * the seam is the trait call `Integrator::ray_colour(&self, Ray, &Scene, i32) -> DVec3`
+ * (renderer/src/integrator.rs:6-8) made once per camera sample from the tile loop
+ * (desktop/src/main.rs:978-1019), plus `Hittable::hit` for `Scene` (renderer/src/scene.rs:31-38).
+ * A per-ray FFI call is useless for a GPU, so the boundary is batched:
+ *   rt_trace_closest  == Scene::hit            (scene.rs:31-38 -> bvh.rs:91-106 / hittable.rs:41-53) for n rays
+ *   rt_render         == the spp loop of main.rs:991-1007 calling ray_colour (integrator.rs:31-397)
+ *                        for every pixel over a range of sample indices, summed per pixel
+ *   rt_resolve        == main.rs:1009-1013 (mean, aces_tonemapping main.rs:913-921) + Image::put NaN scrub (image.rs:43-59)
+ *   rt_scene_upload   == handing `&Scene` (scene.rs:11-17) to the integrator, as one flattened blob
+ * INTEGRATION.md shows the Rust `extern "C"` block that binds these.
+ *
+ * Conventions: 0 = ok, negative = error class; message via rt_last_error() (thread-local).  Every
+ * pointer argument is caller-owned and only borrowed for the duration of the call.  Handles are
+ * library-owned and freed only by their _destroy.  A context is bound to one device and is not
+ * thread-safe: one host thread (or process) per GPU.  Pointers documented "device" must be device
+ * memory of the context's GPU (e.g. a torch CUDA tensor's data_ptr); all others are host memory.
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_ERR_BAD_ARG (-1)
+#define RT_ERR_HIP (-2)
+#define RT_ERR_OOM (-3)
+#define RT_ERR_UNSUPPORTED (-4)
+#define RT_ERR_BAD_BLOB (-5)
+
+#define RT_NONE 0xFFFFFFFFu
+
+/* integrator ids (renderer/src/integrator.rs) */
+#define RT_INT_MIS 0      /* MultipleImportanceSampleIntegrator   integrator.rs:29-171  */
+#define RT_INT_LIGHT_IS 1 /* ImportanceSampleLightIntegrator      integrator.rs:172-260 */
+#define RT_INT_BRDF 2     /* BRDFSampledPathIntegrator            integrator.rs:262-327 */
+#define RT_INT_UNIFORM 3  /* UniformSampledPathIntegrator         integrator.rs:329-397 */
+
+/* background ids: `fn(Ray)->DVec3` cannot cross a C ABI, so the two functions the reference
+ * defines become an enum (desktop/src/main.rs:37-48) */
+#define RT_BG_BLACK 0 /* no_light */
+#define RT_BG_SKY 1   /* skybox   */
+
+/* ---------------------------------------------------------------------------------------------
+ * Flattened scene blob ("RTSB" v1): one contiguous, position-independent byte range -> one
+ * hipMemcpy, one broadcast.  Produced host-side by librt_host.so (Scene::flatten); layout below.
+ * All offsets are bytes from the start of the blob and 16-byte aligned.
+ * ------------------------------------------------------------------------------------------- */
+#define RT_BLOB_MAGIC 0x42535452u
+#define RT_BLOB_VERSION 1u
+
+/* Threaded BVH node, 64 B, pre-order (DFS, left first): the reference's fixed left-then-right
+ * recursion (bvh.rs:91-106) needs no per-lane stack once every node stores where to go when its
+ * box test fails (`skip` = index of the next node in pre-order outside this subtree). */
+typedef struct rt_node {
+    double bmin[3], bmax[3];
+    uint32_t skip;   /* next node index when the box test fails (== n_nodes of the sub-array at the end) */
+    uint32_t flags;  /* RT_NODE_NO_BOX: linear-list item (hittable.rs:41-53), no box test */
+    uint32_t prim0;  /* leaf node: first primitive (bvh.rs left), RT_NONE for an inner node */
+    uint32_t prim1;  /* leaf node: second primitive (bvh.rs right), RT_NONE if absent or == prim0 */
+} rt_node;
+#define RT_NODE_NO_BOX 1u
+
+#define RT_PRIM_TRIANGLE 0u
+#define RT_PRIM_SPHERE 1u
+#define RT_PRIM_MOVING_SPHERE 2u
+#define RT_PRIM_AARECT 3u
+#define RT_PRIM_INSTANCE 4u /* BVHNode object, optionally under a Transformed (main.rs:161-188) */
+
+typedef struct rt_prim {
+    uint32_t kind;
+    uint32_t index;     /* into the kind's table; INSTANCE: first node of the sub-BVH */
+    uint32_t xform;     /* rt_xform index of the enclosing Transformed, or RT_NONE */
+    uint32_t material;  /* rt_material index (RT_NONE for INSTANCE) */
+    uint32_t object_id; /* id of the primitive object in the scene description */
+    uint32_t inst_id;   /* id of the enclosing Transformed object, or RT_NONE */
+    uint32_t sub_end;   /* INSTANCE: one past the last node of the sub-BVH */
+    uint32_t pad;
+} rt_prim;
+
+typedef struct rt_tri_verts { double v0[3], v1[3], v2[3]; } rt_tri_verts;                 /* 72 B  */
+typedef struct rt_tri_attrs { double n0[3], n1[3], n2[3]; double uv0[2], uv1[2], uv2[2]; } rt_tri_attrs; /* 120 B */
+typedef struct rt_sphere { double center[3]; double radius; } rt_sphere;                  /* 32 B  */
+typedef struct rt_moving_sphere { double center0[3], center1[3]; double time0, time1, radius; } rt_moving_sphere; /* 72 B */
+typedef struct rt_aarect { double x0, x1, y0, y1, z; } rt_aarect;                         /* 40 B  */
+typedef struct rt_xform { double t_inv[16]; } rt_xform; /* column-major inverse of the Transformed matrix (transform.rs:14-20) */
+
+#define RT_MAT_LAMBERTIAN 0u
+#define RT_MAT_METAL 1u
+#define RT_MAT_DIELECTRIC 2u
+#define RT_MAT_DIFFUSE_LIGHT 3u
+typedef struct rt_material {
+    uint32_t kind;
+    uint32_t texture;  /* albedo (LAMBERTIAN) / emit_colour (DIFFUSE_LIGHT) */
+    double albedo[3];  /* METAL */
+    double fuzz;       /* METAL, already clamped to <= 1 (material.rs:55-62) */
+    double ior;        /* DIELECTRIC */
+} rt_material;
+
+#define RT_TEX_SOLID 0u
+#define RT_TEX_CHECKER 1u
+#define RT_TEX_IMAGE 2u
+typedef struct rt_texture {
+    uint32_t kind;
+    uint32_t a;  /* CHECKER: odd texture  | IMAGE: byte offset of the first texel in the texel pool */
+    uint32_t b;  /* CHECKER: even texture | IMAGE: width  */
+    uint32_t c;  /*                         IMAGE: height */
+    double colour[3]; /* SOLID */
+} rt_texture;
+/* texel pool: RGB8 bytes; the device computes (byte/255)^2 in f64 per fetch, bit-identical to the
+ * reference's load_texture table (main.rs:900-903) at 1/8 of its footprint */
+
+typedef struct rt_light { /* scene.lights entry: only Sphere implements SampleableLight (shape.rs:36-53) */
+    double center[3];
+    double radius;
+    uint32_t material;
+    uint32_t object_id;
+} rt_light;
+
+typedef struct rt_camera { /* renderer/src/camera.rs:9-19 */
+    double origin[3], lower_left_corner[3], horizontal[3], vertical[3], u[3], v[3];
+    double lens_radius, time0, time1;
+} rt_camera;
+
+typedef struct rt_blob_header {
+    uint32_t magic, version;
+    uint64_t total_bytes;
+    uint32_t n_nodes, n_prims, n_tris, n_spheres, n_moving_spheres, n_rects, n_xforms, n_materials, n_textures, n_lights;
+    uint32_t n_texel_bytes;
+    uint32_t root_node; /* first node of the scene-level traversal (BVH root or first list item) */
+    uint32_t root_end;  /* one past the last node of the scene-level traversal */
+    uint32_t background;
+    uint64_t off_nodes, off_prims, off_tri_verts, off_tri_attrs, off_spheres, off_moving_spheres, off_rects, off_xforms,
+        off_materials, off_textures, off_texels, off_lights;
+    rt_camera camera;
+    uint64_t bvh_seed;
+} rt_blob_header;
+
+/* ---------------------------------------------------------------------------------------------
+ * Entry points
+ * ------------------------------------------------------------------------------------------- */
+typedef struct rt_context rt_context;
+typedef struct rt_scene rt_scene;
+
+typedef struct rt_render_params {
+    uint32_t width, height;
+    uint32_t spp_begin, spp_end; /* absolute sample indices [begin, end): rank r of R renders its own slice */
+    int32_t max_depth;           /* main.rs:944 */
+    int32_t integrator;          /* RT_INT_* */
+    uint64_t seed;               /* Philox key; counter = (pixel, sample, level, block) */
+    uint32_t samples_per_pass;   /* 0 = library default; paths in flight = width*height*samples_per_pass */
+    uint32_t flags;              /* RT_RENDER_* */
+} rt_render_params;
+#define RT_RENDER_COUNT_TESTS 1u /* also count box/primitive tests (slower kernel variant) */
+#define RT_RENDER_NO_SORT 2u     /* disable the material-binned queue (debug / A-B) */
+
+typedef struct rt_stats {
+    uint64_t rays;       /* Scene::hit-equivalent closest-hit queries: camera + bounce + MIS shadow rays */
+    uint64_t paths;      /* camera samples = width*height*(spp_end-spp_begin) */
+    uint64_t box_tests;  /* only with RT_RENDER_COUNT_TESTS / rt_trace_closest counters */
+    uint64_t tri_tests;
+    uint64_t sphere_tests;
+    uint64_t launches;   /* kernel launches issued */
+    double ms_total;     /* first ray-gen launch -> accumulators final (HIP events on the context stream) */
+    double ms_trace;     /* sum over trace_closest launches (HIP events) */
+    double ms_shade;     /* sum over shade launches */
+    double ms_other;     /* raygen + unwind/accumulate + queue upkeep */
+    uint64_t trace_launches;
+} rt_stats;
+
+/* number of visible HIP devices (>= 0) or negative error */
+int rt_device_count(void);
+/* Creates a context on `device` with its own stream.  `stream` may be a caller hipStream_t (cast
+ * to void*, e.g. torch.cuda.current_stream().cuda_stream) or NULL for a library-owned stream. */
+int rt_context_create(int device, void* stream, rt_context** out);
+int rt_context_destroy(rt_context* ctx);
+int rt_context_synchronize(rt_context* ctx);
+
+/* Validates and copies the flattened blob to the device (caller keeps `blob`). */
+int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene** out);
+int rt_scene_destroy(rt_scene* scene);
+
+/* Scene::hit for n rays (scene.rs:31-38).  rays: n x 7 doubles (ox,oy,oz,dx,dy,dz,time), host.
+ * Outputs (host): prim_id = object id of the closest primitive or RT_NONE; inst_id = enclosing
+ * Transformed object id or RT_NONE (may be NULL); t = ray parameter (0 on miss).
+ * counters (host, may be NULL): 3 x u64 = box, triangle, sphere tests summed over the batch. */
+int rt_trace_closest(rt_scene* scene, uint32_t n, const double* rays, double t_min, double t_max,
+                     uint32_t* prim_id, uint32_t* inst_id, double* t, uint64_t* counters);
+/* Same, everything already resident: rays_dev n x 7 doubles, outputs device arrays; asynchronous on
+ * the context stream.  This is the entry bench.py times for the traversal kernel alone. */
+int rt_trace_closest_device(rt_scene* scene, uint32_t n, const double* rays_dev, double t_min, double t_max,
+                            uint32_t* prim_id_dev, double* t_dev);
+
+/* Camera rays (main.rs:996-999 + camera.rs:83-101) of one sample index for every pixel, written
+ * to host `rays` (width*height x 7 doubles, row 0 = bottom row). */
+int rt_primary_rays(rt_scene* scene, uint32_t width, uint32_t height, uint32_t sample, uint64_t seed, double* rays);
+
+/* Renders samples [spp_begin, spp_end) of every pixel and ADDS the per-pixel radiance SUM (not the
+ * mean) into accum_dev: device, width*height*3 fp32, row 0 = bottom row.  The caller zeroes it
+ * (rt_accum_zero) before the first call; calls may be chained over disjoint sample ranges; ranks
+ * all-reduce(sum) their accumulators before rt_resolve.  Synchronous: returns when accum is final. */
+int rt_render(rt_scene* scene, const rt_render_params* params, float* accum_dev, rt_stats* stats);
+int rt_accum_zero(rt_context* ctx, float* accum_dev, uint32_t width, uint32_t height);
+/* Host-memory convenience for callers without device allocations (the `desktop` app): allocates a
+ * device accumulator internally, renders, copies the sums to host accum (width*height*3 fp32). */
+int rt_render_host(rt_scene* scene, const rt_render_params* params, float* accum_host, rt_stats* stats);
+
+/* accum sums -> displayable pixels: /spp, optional ACES (main.rs:913-921), NaN channel -> 0
+ * (image.rs:48-56).  Device in, device out (width*height*3 fp32; may alias). */
+int rt_resolve(rt_context* ctx, const float* accum_dev, uint32_t width, uint32_t height, uint32_t spp, int tonemap,
+               float* out_dev);
+int rt_resolve_host(const float* accum_host, uint32_t width, uint32_t height, uint32_t spp, int tonemap, float* out_host);
+
+/* Radiance of individual camera samples, f64, no accumulation: out_rgb (host, n x 3 doubles) for
+ * samples (pixel_index[i], sample_index[i]).  Used by the parity tests to compare single paths. */
+int rt_sample_radiance(rt_scene* scene, uint32_t width, uint32_t height, uint32_t n, const uint32_t* pixel_index,
+                       const uint32_t* sample_index, int32_t max_depth, int32_t integrator, uint64_t seed, double* out_rgb);
+
+/* IEEE check helper: q[i] = a[i]/b[i], s[i] = sqrt(a[i]) computed on the device with the same
+ * compiler flags as the kernels (host arrays). */
+int rt_ieee_div_sqrt(rt_context* ctx, uint32_t n, const double* a, const double* b, double* q, double* s);
+
+const char* rt_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_ABI_H */

@@ -1,0 +1,193 @@
+"""raytracing_amd -- MI355X-native `ray_colour` path.
+
+Thin Python face over the two C libraries:
+  librt_host.so  host-side scene construction, BVH build (bvh.rs:36-87) and flattening
+  librt_hip.so   gfx950 kernels behind the C ABI of include/rt_abi.h
+Nothing here computes: numpy only carries buffers.  Missing librt_hip.so raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import ASSETS, RenderParams, Stats
+
+INT_MIS, INT_LIGHT_IS, INT_BRDF, INT_UNIFORM = 0, 1, 2, 3
+INTEGRATORS = {"mis": INT_MIS, "light_is": INT_LIGHT_IS, "brdf": INT_BRDF, "uniform": INT_UNIFORM}
+NONE = 0xFFFFFFFF
+RENDER_COUNT_TESTS, RENDER_NO_SORT = 1, 2
+
+
+class RtError(RuntimeError):
+    pass
+
+
+def _host_err():
+    return RtError("librt_host: " + _ffi.host().rth_last_error().decode())
+
+
+def _hip_check(rc):
+    if rc != 0:
+        raise RtError(f"librt_hip rc={rc}: " + _ffi.hip().rt_last_error().decode())
+
+
+class HostScene:
+    """A scene graph held by librt_host.so (renderer::Scene)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise _host_err()
+        self._h = handle
+
+    @classmethod
+    def builtin(cls, name, bvh_seed=0, legacy_bvh=False, assets=ASSETS):
+        L = _ffi.host()
+        L.rth_set_bvh_axis_seed(bvh_seed)
+        return cls(L.rth_scene_builtin(name.encode(), assets.encode(), 1 if legacy_bvh else 0))
+
+    @classmethod
+    def from_description(cls, text):
+        b = text.encode() if isinstance(text, str) else text
+        return cls(_ffi.host().rth_scene_from_description(b, len(b)))
+
+    def describe(self):
+        n = _ffi.u64()
+        p = _ffi.host().rth_scene_describe(self._h, C.byref(n))
+        if not p:
+            raise _host_err()
+        return C.string_at(p, n.value)
+
+    def blob(self):
+        n = _ffi.u64()
+        p = _ffi.host().rth_scene_flatten(self._h, C.byref(n))
+        if not p:
+            raise _host_err()
+        return C.string_at(p, n.value)
+
+    def header(self):
+        return _ffi.BlobHeader.from_buffer_copy(self.blob()[:C.sizeof(_ffi.BlobHeader)])
+
+    def nodes(self):
+        b, h = self.blob(), self.header()
+        return np.frombuffer(b, dtype=np.dtype([("bmin", "<f8", 3), ("bmax", "<f8", 3), ("skip", "<u4"), ("flags", "<u4"),
+                                                ("prim0", "<u4"), ("prim1", "<u4")]), count=h.n_nodes, offset=h.off_nodes)
+
+    def prims(self):
+        b, h = self.blob(), self.header()
+        return np.frombuffer(b, dtype=np.dtype([("kind", "<u4"), ("index", "<u4"), ("xform", "<u4"), ("material", "<u4"),
+                                                ("object_id", "<u4"), ("inst_id", "<u4"), ("sub_end", "<u4"), ("pad", "<u4")]),
+                             count=h.n_prims, offset=h.off_prims)
+
+    def __del__(self):
+        try:
+            if self._h:
+                _ffi.host().rth_scene_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class Context:
+    """rt_context: one per GPU / process."""
+
+    def __init__(self, device=0, stream=None):
+        L = _ffi.hip()
+        h = C.c_void_p()
+        _hip_check(L.rt_context_create(device, C.c_void_p(stream) if stream else None, C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def upload(self, scene):
+        blob = scene.blob() if isinstance(scene, HostScene) else scene
+        return GpuScene(self, blob)
+
+    def synchronize(self):
+        _hip_check(_ffi.hip().rt_context_synchronize(self._h))
+
+    def accum_zero(self, accum_ptr, width, height):
+        _hip_check(_ffi.hip().rt_accum_zero(self._h, C.c_void_p(accum_ptr), width, height))
+
+    def resolve(self, accum_ptr, width, height, spp, tonemap, out_ptr):
+        _hip_check(_ffi.hip().rt_resolve(self._h, C.c_void_p(accum_ptr), width, height, spp, int(tonemap), C.c_void_p(out_ptr)))
+
+    def ieee_div_sqrt(self, a, b):
+        a = np.ascontiguousarray(a, np.float64); b = np.ascontiguousarray(b, np.float64)
+        q = np.empty_like(a); s = np.empty_like(a)
+        _hip_check(_ffi.hip().rt_ieee_div_sqrt(self._h, a.size, a.ctypes.data, b.ctypes.data, q.ctypes.data, s.ctypes.data))
+        return q, s
+
+    def close(self):
+        if self._h:
+            _ffi.hip().rt_context_destroy(self._h)
+            self._h = None
+
+
+class GpuScene:
+    """rt_scene: the flattened blob resident in HBM."""
+
+    def __init__(self, ctx, blob):
+        h = C.c_void_p()
+        _hip_check(_ffi.hip().rt_scene_upload(ctx._h, blob, len(blob), C.byref(h)))
+        self._h = h
+        self.ctx = ctx
+
+    def trace_closest(self, rays, t_min, t_max, counters=False):
+        rays = np.ascontiguousarray(rays, np.float64).reshape(-1, 7)
+        n = rays.shape[0]
+        prim = np.empty(n, np.uint32); inst = np.empty(n, np.uint32); t = np.empty(n, np.float64)
+        cnt = np.zeros(3, np.uint64)
+        _hip_check(_ffi.hip().rt_trace_closest(self._h, n, rays.ctypes.data, t_min, t_max, prim.ctypes.data, inst.ctypes.data,
+                                               t.ctypes.data, cnt.ctypes.data if counters else None))
+        return (prim, inst, t, cnt) if counters else (prim, inst, t)
+
+    def trace_closest_device(self, n, rays_ptr, t_min, t_max, prim_ptr, t_ptr):
+        _hip_check(_ffi.hip().rt_trace_closest_device(self._h, n, C.c_void_p(rays_ptr), t_min, t_max, C.c_void_p(prim_ptr), C.c_void_p(t_ptr)))
+
+    def primary_rays(self, width, height, sample, seed):
+        rays = np.empty((width * height, 7), np.float64)
+        _hip_check(_ffi.hip().rt_primary_rays(self._h, width, height, sample, seed, rays.ctypes.data))
+        return rays
+
+    def _params(self, width, height, spp_begin, spp_end, max_depth, integrator, seed, samples_per_pass, flags):
+        return RenderParams(width, height, spp_begin, spp_end, max_depth, integrator, seed, samples_per_pass, flags)
+
+    def render(self, accum_ptr, width, height, spp_begin, spp_end, max_depth, integrator, seed=0x5EED, samples_per_pass=0, flags=0):
+        """Adds radiance sums of samples [spp_begin, spp_end) into the DEVICE fp32 accumulator at accum_ptr."""
+        p = self._params(width, height, spp_begin, spp_end, max_depth, integrator, seed, samples_per_pass, flags)
+        st = Stats()
+        _hip_check(_ffi.hip().rt_render(self._h, C.byref(p), C.c_void_p(accum_ptr), C.byref(st)))
+        return st
+
+    def render_host(self, width, height, spp_begin, spp_end, max_depth, integrator, seed=0x5EED, samples_per_pass=0, flags=0):
+        p = self._params(width, height, spp_begin, spp_end, max_depth, integrator, seed, samples_per_pass, flags)
+        st = Stats()
+        acc = np.zeros((height, width, 3), np.float32)
+        _hip_check(_ffi.hip().rt_render_host(self._h, C.byref(p), acc.ctypes.data, C.byref(st)))
+        return acc, st
+
+    def sample_radiance(self, width, height, pixel_index, sample_index, max_depth, integrator, seed=0x5EED):
+        px = np.ascontiguousarray(pixel_index, np.uint32); sm = np.ascontiguousarray(sample_index, np.uint32)
+        out = np.empty((px.size, 3), np.float64)
+        _hip_check(_ffi.hip().rt_sample_radiance(self._h, width, height, px.size, px.ctypes.data, sm.ctypes.data, max_depth, integrator,
+                                                 seed, out.ctypes.data))
+        return out
+
+    def close(self):
+        if self._h:
+            _ffi.hip().rt_scene_destroy(self._h)
+            self._h = None
+
+
+def resolve_host(accum, spp, tonemap=True):
+    accum = np.ascontiguousarray(accum, np.float32)
+    h, w = accum.shape[:2]
+    out = np.empty_like(accum)
+    _hip_check(_ffi.hip().rt_resolve_host(accum.ctypes.data, w, h, spp, int(tonemap), out.ctypes.data))
+    return out
+
+
+def write_ppm(path, rgb):
+    rgb = np.ascontiguousarray(rgb, np.float64)
+    h, w = rgb.shape[:2]
+    if _ffi.host().rth_write_ppm(path.encode(), rgb.ctypes.data, w, h) != 0:
+        raise _host_err()

@@ -1,0 +1,982 @@
+// librt_hip.so -- gfx950 kernels + the C ABI of include/rt_abi.h.
+//
+// Pipeline (one "pass" = every pixel x samples_per_pass camera samples in flight):
+//   k_raygen  -> [ k_trace(path rays) -> k_shade -> k_trace(shadow rays) ] x max_depth -> k_unwind -> k_accumulate
+// * k_trace is a WAVE-COHERENT threaded-BVH walk: the 64 rays of a wave advance through the
+//   pre-order node array together; the node index is wave-uniform, so nodes / primitives / vertices
+//   arrive by scalar loads (one fetch per wave) and all 64 lanes spend their VALU slots on the f64
+//   slab / Moller-Trumbore arithmetic.  Each lane keeps only "the next node I need" (its private
+//   skip target); the wave jumps to the minimum over lanes.  The order in which a lane sees nodes,
+//   and the t_max it carries, are exactly the reference recursion's (bvh.rs:91-106), so the closest
+//   hit (primitive, t) is bit-identical by construction.
+// * k_shade evaluates one ray_colour level (integrator.rs) per live path, writes a bounce record,
+//   the next ray and (MIS) the shadow ray, and compacts survivors into the next queue with a
+//   wave64 ballot + popcount prefix and ONE atomic per wave.
+// * k_unwind applies the records last-to-first (the MIS weight gate depends on the returned
+//   sub-path radiance, integrator.rs:119-136, so a running throughput cannot express it).
+#include "rt_scene.h"
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace rt;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_OK(expr)                                                                                              \
+    do {                                                                                                          \
+        hipError_t e_ = (expr);                                                                                   \
+        if (e_ != hipSuccess)                                                                                     \
+            return fail(e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// wave helpers
+// ------------------------------------------------------------------------------------------------
+RT_DEV uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+        v = o < v ? o : v;
+    }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+RT_DEV uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, off, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), off, 64);
+        v += ((uint64_t)hi << 32) | lo;
+    }
+    return v;
+}
+RT_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// ------------------------------------------------------------------------------------------------
+// k_trace: Scene::hit (scene.rs:31-38 -> bvh.rs:91-106 / hittable.rs:41-53) for a queue of rays
+// ------------------------------------------------------------------------------------------------
+struct LaneHit {
+    double best;         // current t_max (bvh.rs:98-101)
+    uint32_t prim, inst; // indices into the prims table
+};
+struct LaneCount { uint32_t box, tri, sph; };
+
+template <int LEVEL, bool COUNT>
+RT_DEV void traverse(const SceneDev& sc, uint32_t first, uint32_t end, d3 o, d3 d, double time, bool active, double t_min,
+                     LaneHit& h, uint32_t inst_prim, LaneCount& cnt);
+
+template <int LEVEL, bool COUNT>
+RT_DEV void test_prim(const SceneDev& sc, uint32_t p, bool pass, d3 o, d3 d, double time, double t_min, LaneHit& h, uint32_t inst_prim,
+                      uint32_t& cached_xf, d3& xo, d3& xd, LaneCount& cnt) {
+    const RT_CONST rt_prim& pr = as_const(sc.prims)[p];  // wave-uniform -> scalar load
+    const uint32_t kind = pr.kind, index = pr.index, xf = pr.xform;
+    d3 ro = o, rd = d;
+    if (xf != RT_NONE) {  // transform.rs:25-32; one transform per (ray, distinct matrix): the pagoda wraps every triangle in the same one
+        if (xf != cached_xf) {
+            cptr<double> m = as_const(sc.xforms[xf].t_inv);
+            double mm[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) mm[k] = m[k];
+            xo = mat_mul_xyz(mm, o, 1.0);
+            xd = mat_mul_xyz(mm, d, 0.0);
+            cached_xf = xf;
+        }
+        ro = xo; rd = xd;
+    }
+    double t;
+    if (kind == RT_PRIM_TRIANGLE) {
+        const RT_CONST rt_tri_verts& tv = as_const(sc.tri_verts)[index];
+        d3 v0 = mk(tv.v0[0], tv.v0[1], tv.v0[2]), v1 = mk(tv.v1[0], tv.v1[1], tv.v1[2]), v2 = mk(tv.v2[0], tv.v2[1], tv.v2[2]);
+        double u, v;
+        if (COUNT) cnt.tri += pass ? 1u : 0u;
+        if (pass && tri_hit(v0, v1, v2, ro, rd, t_min, h.best, t, u, v)) { h.best = t; h.prim = p; h.inst = inst_prim; }
+    } else if (kind == RT_PRIM_SPHERE) {
+        const RT_CONST rt_sphere& s = as_const(sc.spheres)[index];
+        if (COUNT) cnt.sph += pass ? 1u : 0u;
+        if (pass && sphere_hit(mk(s.center[0], s.center[1], s.center[2]), s.radius, ro, rd, t_min, h.best, t)) { h.best = t; h.prim = p; h.inst = inst_prim; }
+    } else if (kind == RT_PRIM_MOVING_SPHERE) {
+        const RT_CONST rt_moving_sphere& s = as_const(sc.moving)[index];
+        if (COUNT) cnt.sph += pass ? 1u : 0u;
+        d3 c = moving_center(mk(s.center0[0], s.center0[1], s.center0[2]), mk(s.center1[0], s.center1[1], s.center1[2]), s.time0, s.time1, time);
+        if (pass && sphere_hit(c, s.radius, ro, rd, t_min, h.best, t)) { h.best = t; h.prim = p; h.inst = inst_prim; }
+    } else if (kind == RT_PRIM_AARECT) {
+        const RT_CONST rt_aarect& a = as_const(sc.rects)[index];
+        if (pass && rect_hit(a.x0, a.x1, a.y0, a.y1, a.z, ro, rd, t_min, h.best, t)) { h.best = t; h.prim = p; h.inst = inst_prim; }
+    } else if constexpr (LEVEL == 0) {  // RT_PRIM_INSTANCE: BVHNode object (optionally under a Transformed), main.rs:161-188
+        traverse<1, COUNT>(sc, index, pr.sub_end, ro, rd, time, pass, t_min, h, p, cnt);
+    }
+}
+
+template <int LEVEL, bool COUNT>
+RT_DEV void traverse(const SceneDev& sc, uint32_t first, uint32_t end, d3 o, d3 d, double time, bool active, double t_min,
+                     LaneHit& h, uint32_t inst_prim, LaneCount& cnt) {
+    const d3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);  // bounding_box.rs:29
+    uint32_t next = active ? first : 0xFFFFFFFFu;          // per lane: the next node this ray must visit
+    uint32_t i = first;                                    // wave-uniform cursor
+    uint32_t cached_xf = RT_NONE;
+    d3 xo = o, xd = d;
+    cptr<rt_node> nodes = as_const(sc.nodes);
+    while (i < end) {
+        const RT_CONST rt_node& nd = nodes[i];
+        const uint32_t flags = nd.flags, skip = nd.skip, p0 = nd.prim0, p1 = nd.prim1;
+        const bool act = next == i;
+        bool pass = act;
+        if (!(flags & RT_NODE_NO_BOX)) {
+            if (COUNT) cnt.box += act ? 1u : 0u;
+            bool bx = box_axis(nd.bmin[0], nd.bmax[0], o.x, inv.x, t_min, h.best);
+            bool by = box_axis(nd.bmin[1], nd.bmax[1], o.y, inv.y, t_min, h.best);
+            bool bz = box_axis(nd.bmin[2], nd.bmax[2], o.z, inv.z, t_min, h.best);
+            pass = act & bx & by & bz;
+        }
+        next = act ? (pass ? i + 1u : skip) : next;
+        if (p0 != RT_NONE && __ballot(pass) != 0ull) {
+            test_prim<LEVEL, COUNT>(sc, p0, pass, o, d, time, t_min, h, inst_prim, cached_xf, xo, xd, cnt);
+            if (p1 != RT_NONE) test_prim<LEVEL, COUNT>(sc, p1, pass, o, d, time, t_min, h, inst_prim, cached_xf, xo, xd, cnt);
+        }
+        if (__ballot(next == i + 1u) != 0ull) i = i + 1u;
+        else i = wave_min_u32(next);
+    }
+}
+
+// rays: SoA [7][cap] (ox,oy,oz,dx,dy,dz,time) indexed by path; outputs indexed by path.
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_trace(SceneDev sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_fixed,
+                                               const double* __restrict__ rays, uint32_t cap, double t_min, double t_max,
+                                               uint32_t* __restrict__ out_prim, uint32_t* __restrict__ out_inst, double* __restrict__ out_t,
+                                               unsigned long long* __restrict__ stats) {
+    const uint32_t n = n_ptr ? *n_ptr : n_fixed;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t wave_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(gid & ~63u));
+    if (gid == 0 && stats) atomicAdd(&stats[0], (unsigned long long)n);  // rays traced
+    if (wave_first >= n) return;
+    const bool valid = gid < n;
+    const uint32_t path = valid ? (queue ? queue[gid] : gid) : 0u;
+    d3 o = mk(0, 0, 0), d = mk(1, 1, 1);
+    double time = 0.0;
+    if (valid) {
+        o = mk(rays[0 * (size_t)cap + path], rays[1 * (size_t)cap + path], rays[2 * (size_t)cap + path]);
+        d = mk(rays[3 * (size_t)cap + path], rays[4 * (size_t)cap + path], rays[5 * (size_t)cap + path]);
+        time = rays[6 * (size_t)cap + path];
+    }
+    LaneHit h; h.best = t_max; h.prim = RT_NONE; h.inst = RT_NONE;
+    LaneCount cnt; cnt.box = cnt.tri = cnt.sph = 0;
+    traverse<0, COUNT>(sc, sc.root_node, sc.root_end, o, d, time, valid, t_min, h, RT_NONE, cnt);
+    if (valid) {
+        out_prim[path] = h.prim;
+        if (out_inst) out_inst[path] = h.inst;
+        out_t[path] = h.prim != RT_NONE ? h.best : __builtin_nan("");
+    }
+    if (COUNT && stats) {
+        uint64_t b = wave_sum_u64(cnt.box), t = wave_sum_u64(cnt.tri), s = wave_sum_u64(cnt.sph);
+        if (lane_id() == 0) { atomicAdd(&stats[1], (unsigned long long)b); atomicAdd(&stats[2], (unsigned long long)t); atomicAdd(&stats[3], (unsigned long long)s); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_raygen: main.rs:996-999 + camera.rs:83-101
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_raygen(rt_camera cam, uint32_t width, uint32_t height, uint32_t n, uint32_t sample0, uint32_t npix,
+                                                const uint32_t* __restrict__ in_pixel, const uint32_t* __restrict__ in_sample, uint64_t seed,
+                                                double* __restrict__ rays, uint32_t cap, uint32_t* __restrict__ path_pixel, uint32_t* __restrict__ path_sample,
+                                                uint32_t* __restrict__ nb) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t pixel = in_pixel ? in_pixel[p] : p % npix;
+    const uint32_t sample = in_sample ? in_sample[p] : sample0 + p / npix;
+    const uint32_t x = pixel % width, y = pixel / width;
+    Rng rng(seed, pixel, sample, 0u);
+    const double u = ((double)x + rng.next_f64()) / (double)(width - 1);
+    const double v = ((double)y + rng.next_f64()) / (double)(height - 1);
+    const d3 cu = ld3(cam.u), cv = ld3(cam.v), origin = ld3(cam.origin);
+    d3 random_in_lens = rand_in_unit_sphere(rng) * cam.lens_radius;
+    d3 offset = (cu * random_in_lens.x) + (cv * random_in_lens.y);
+    double time = (cam.time1 - cam.time0) > 0.000001 ? rng.range(cam.time0, cam.time1) : 0.0;
+    d3 ro = origin + offset;
+    d3 rd = ld3(cam.lower_left_corner) + (ld3(cam.horizontal) * u) + (ld3(cam.vertical) * v) - origin - offset;
+    rays[0 * (size_t)cap + p] = ro.x; rays[1 * (size_t)cap + p] = ro.y; rays[2 * (size_t)cap + p] = ro.z;
+    rays[3 * (size_t)cap + p] = rd.x; rays[4 * (size_t)cap + p] = rd.y; rays[5 * (size_t)cap + p] = rd.z;
+    rays[6 * (size_t)cap + p] = time;
+    path_pixel[p] = pixel; path_sample[p] = sample;
+    if (nb) nb[p] = 0u;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_shade: one ray_colour level (integrator.rs) for every live path
+// ------------------------------------------------------------------------------------------------
+// Bounce record, SoA [depth][REC_FIELDS][cap].  With emitted == 0 for every scattering material:
+//   not visible / no light sample:  L = (brdf*cos*L_next)/pdf              (integrator.rs:62-66,164-168,224,291,361)
+//   light visible (MIS):            L = (brdf*cos*L_next*w)/pdf + C_l      (integrator.rs:138-154), w gated by L_next >= .001
+enum { REC_BRDF_X = 0, REC_BRDF_Y, REC_BRDF_Z, REC_COS, REC_PDF, REC_W, REC_CL_X, REC_CL_Y, REC_CL_Z, REC_T_LIGHT, REC_T_SHADOW, REC_FIELDS };
+
+struct PathBuffers {
+    double* rays;        // [7][cap]
+    double* shadow_rays; // [7][cap]
+    uint32_t* hit_prim; uint32_t* hit_inst; double* hit_t;
+    uint32_t* shadow_prim;
+    uint32_t* path_pixel; uint32_t* path_sample;
+    uint32_t* nb;        // records written per path
+    double* terminal;    // [3][cap] radiance returned by the last ray_colour level
+    double* records;     // [depth][REC_FIELDS][cap]
+    double* radiance;    // [3][cap]
+    uint32_t cap;
+};
+
+RT_DEV void push_queue(bool want, uint32_t path, uint32_t* __restrict__ queue, uint32_t* __restrict__ count) {
+    const uint64_t m = __ballot(want);
+    if (m == 0ull) return;
+    uint32_t base = 0;
+    const uint32_t lane = lane_id();
+    const uint32_t leader = (uint32_t)__builtin_ctzll(m);
+    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, (int)leader, 64);
+    if (want) queue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = path;
+}
+
+__global__ __launch_bounds__(256) void k_shade(SceneDev sc, PathBuffers pb, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr,
+                                               uint32_t bounce, int32_t max_depth, int32_t integrator, uint64_t seed,
+                                               uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_count,
+                                               uint32_t* __restrict__ shadow_queue, uint32_t* __restrict__ shadow_count) {
+    const uint32_t n = *n_ptr;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((gid & ~63u) >= n) return;
+    const bool valid = gid < n;
+    const uint32_t cap = pb.cap;
+    bool want_next = false, want_shadow = false;
+    uint32_t path = 0;
+    if (valid) {
+        path = queue[gid];
+        Ray ray;
+        ray.o = mk(pb.rays[0 * (size_t)cap + path], pb.rays[1 * (size_t)cap + path], pb.rays[2 * (size_t)cap + path]);
+        ray.d = mk(pb.rays[3 * (size_t)cap + path], pb.rays[4 * (size_t)cap + path], pb.rays[5 * (size_t)cap + path]);
+        ray.time = pb.rays[6 * (size_t)cap + path];
+        const uint32_t prim = pb.hit_prim[path];
+        d3 terminal = mk(0.0, 0.0, 0.0);
+        bool done = false;
+        HitRecord hr;
+        if (prim == RT_NONE) { terminal = background_colour(sc.background, ray); done = true; }  // integrator.rs:39-41
+        else if (!full_hit(sc, prim, pb.hit_inst[path], ray, 0.001, pb.hit_t[path], hr)) { terminal = mk(__builtin_nan(""), __builtin_nan(""), __builtin_nan("")); done = true; }  // cannot happen: poison loudly
+        if (!done) {
+            const rt_material mat = sc.materials[hr.material];
+            Pdf material_pdf;
+            if (!scattering_pdf(mat, ray, hr, material_pdf)) {  // DiffuseLight: return emitted (integrator.rs:45-50)
+                terminal = material_emitted(sc, hr.material, hr.u, hr.v, hr.point);
+                done = true;
+            } else {
+                Rng rng(seed, pb.path_pixel[path], pb.path_sample[path], bounce + 1u);
+                const double nan = __builtin_nan("");
+                d3 brdf, out_dir, c_l = mk(0.0, 0.0, 0.0);
+                double cos_theta, pdf = 1.0, w = 0.0, t_light = nan;
+                const bool delta = pdf_is_delta(material_pdf);
+                if (integrator == RT_INT_MIS) {
+                    if (delta) {  // integrator.rs:54-66
+                        out_dir = normalize(pdf_generate(material_pdf, rng));
+                        cos_theta = dot(out_dir, hr.normal);
+                        brdf = material_brdf(sc, mat, hr, out_dir);
+                    } else {
+                        bool have_light = false;
+                        double light_pdf_value = 0.0;
+                        uint32_t li = 0;
+                        d3 light_dir = mk(0, 0, 0);
+                        if (sc.n_lights > 0u) {  // integrator.rs:68-88
+                            li = rng.index(sc.n_lights);
+                            const rt_light lt = sc.lights[li];
+                            Pdf light_pdf = light_pdf_for_point(lt, hr.point);
+                            light_dir = normalize(pdf_generate(light_pdf, rng));
+                            if (!(dot(hr.normal, light_dir) < 0.0)) {
+                                double tl;
+                                if (sphere_hit(ld3(lt.center), lt.radius, hr.point, light_dir, 0.001, 10000.0, tl)) {
+                                    have_light = true; t_light = tl;
+                                    light_pdf_value = pdf_value(light_pdf, light_dir);
+                                }
+                            }
+                        }
+                        out_dir = normalize(pdf_generate(material_pdf, rng));  // integrator.rs:95 / 158
+                        cos_theta = dot(out_dir, hr.normal);
+                        pdf = pdf_value(material_pdf, out_dir);
+                        brdf = material_brdf(sc, mat, hr, out_dir);
+                        if (have_light) {  // the visible-branch terms (integrator.rs:99-152), used by k_unwind only if the shadow test passes
+                            const rt_light lt = sc.lights[li];
+                            d3 lp = hr.point + light_dir * t_light;          // light_hit.point is unused; (u,v) feed emitted()
+                            d3 ln = (lp - ld3(lt.center)) / lt.radius;
+                            double lu = 0.0, lv = 0.0;
+                            if (material_uses_uv(sc, lt.material)) spherical_uv(ln, lu, lv);
+                            d3 light_emit = material_emitted(sc, lt.material, lu, lv, hr.point);
+                            double th;
+                            bool material_ray_hit_light = sphere_hit(ld3(lt.center), lt.radius, hr.point, out_dir, 0.001, 10000.0, th);
+                            w = power_heuristic(pdf, material_ray_hit_light ? light_pdf_value : 0.0);
+                            double light_weight = power_heuristic(light_pdf_value, pdf_value(material_pdf, light_dir));
+                            double light_cos_theta = fmax(dot(hr.normal, light_dir), 0.0);
+                            c_l = material_brdf(sc, mat, hr, light_dir) * light_cos_theta * light_emit * light_weight / light_pdf_value;
+                            pb.shadow_rays[0 * (size_t)cap + path] = hr.point.x; pb.shadow_rays[1 * (size_t)cap + path] = hr.point.y; pb.shadow_rays[2 * (size_t)cap + path] = hr.point.z;
+                            pb.shadow_rays[3 * (size_t)cap + path] = light_dir.x; pb.shadow_rays[4 * (size_t)cap + path] = light_dir.y; pb.shadow_rays[5 * (size_t)cap + path] = light_dir.z;
+                            pb.shadow_rays[6 * (size_t)cap + path] = ray.time;
+                            want_shadow = true;
+                        }
+                    }
+                } else if (integrator == RT_INT_LIGHT_IS) {  // integrator.rs:187-224 (emitted == 0 here)
+                    Pdf scatter_pdf = material_pdf;
+                    if (!delta && sc.n_lights > 0u) scatter_pdf = light_pdf_for_point(sc.lights[rng.index(sc.n_lights)], hr.point);
+                    out_dir = pdf_generate(scatter_pdf, rng);
+                    cos_theta = dot(out_dir, hr.normal);
+                    if (cos_theta < 0.0) { terminal = mk(0.0, 0.0, 0.0); done = true; }
+                    pdf = pdf_is_delta(scatter_pdf) ? 1.0 : pdf_value(scatter_pdf, out_dir);
+                    brdf = material_brdf(sc, mat, hr, out_dir);
+                } else {  // integrator.rs:273-291 (BRDF) / 340-361 (uniform)
+                    Pdf scatter_pdf = material_pdf;
+                    if (integrator == RT_INT_UNIFORM && !delta) { scatter_pdf.kind = PDF_UNIFORM_HEMI; scatter_pdf.a = hr.normal; }
+                    out_dir = pdf_generate(scatter_pdf, rng);
+                    cos_theta = dot(out_dir, hr.normal);
+                    pdf = pdf_is_delta(scatter_pdf) ? 1.0 : pdf_value(scatter_pdf, out_dir);
+                    brdf = material_brdf(sc, mat, hr, out_dir);
+                }
+                if (!done) {
+                    double* rec = pb.records + (size_t)bounce * REC_FIELDS * cap + path;
+                    rec[REC_BRDF_X * (size_t)cap] = brdf.x; rec[REC_BRDF_Y * (size_t)cap] = brdf.y; rec[REC_BRDF_Z * (size_t)cap] = brdf.z;
+                    rec[REC_COS * (size_t)cap] = cos_theta; rec[REC_PDF * (size_t)cap] = pdf; rec[REC_W * (size_t)cap] = w;
+                    rec[REC_CL_X * (size_t)cap] = c_l.x; rec[REC_CL_Y * (size_t)cap] = c_l.y; rec[REC_CL_Z * (size_t)cap] = c_l.z;
+                    rec[REC_T_LIGHT * (size_t)cap] = t_light;
+                    pb.nb[path] = bounce + 1u;
+                    if ((int32_t)(bounce + 1u) >= max_depth) {  // next level has depth <= 0: returns 0 without tracing (integrator.rs:33-35)
+                        terminal = mk(0.0, 0.0, 0.0);
+                        done = true;
+                    } else {
+                        pb.rays[0 * (size_t)cap + path] = hr.point.x; pb.rays[1 * (size_t)cap + path] = hr.point.y; pb.rays[2 * (size_t)cap + path] = hr.point.z;
+                        pb.rays[3 * (size_t)cap + path] = out_dir.x; pb.rays[4 * (size_t)cap + path] = out_dir.y; pb.rays[5 * (size_t)cap + path] = out_dir.z;
+                        want_next = true;
+                    }
+                }
+            }
+        }
+        if (done) { pb.terminal[0 * (size_t)cap + path] = terminal.x; pb.terminal[1 * (size_t)cap + path] = terminal.y; pb.terminal[2 * (size_t)cap + path] = terminal.z; }
+    }
+    push_queue(want_next, path, next_queue, next_count);
+    push_queue(want_shadow, path, shadow_queue, shadow_count);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_unwind / k_accumulate / k_resolve
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_unwind(PathBuffers pb, uint32_t n) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const size_t cap = pb.cap;
+    d3 L = mk(pb.terminal[0 * cap + p], pb.terminal[1 * cap + p], pb.terminal[2 * cap + p]);
+    for (int k = (int)pb.nb[p] - 1; k >= 0; --k) {
+        const double* rec = pb.records + (size_t)k * REC_FIELDS * cap + p;
+        d3 brdf = mk(rec[REC_BRDF_X * cap], rec[REC_BRDF_Y * cap], rec[REC_BRDF_Z * cap]);
+        double cos_theta = rec[REC_COS * cap], pdf = rec[REC_PDF * cap], t_light = rec[REC_T_LIGHT * cap];
+        bool visible = false;
+        if (t_light == t_light) {  // a light sample was taken: visible iff the shadow ray hit and |t_scene - t_light| <= 1e-4 (integrator.rs:82-86)
+            double t_shadow = rec[REC_T_SHADOW * cap];
+            visible = (t_shadow == t_shadow) && !(fabs(t_shadow - t_light) > 0.0001);
+        }
+        d3 e = mk(0.0, 0.0, 0.0);  // emitted of a scattering material
+        if (visible) {
+            bool has_light = L.x >= 0.001 && L.y >= 0.001 && L.z >= 0.001;  // integrator.rs:119-121
+            double w = has_light ? rec[REC_W * cap] : 0.0;
+            d3 material_contribution = brdf * cos_theta * L * w / pdf;
+            d3 c_l = mk(rec[REC_CL_X * cap], rec[REC_CL_Y * cap], rec[REC_CL_Z * cap]);
+            L = e + material_contribution + c_l;
+        } else {
+            L = e + (brdf * cos_theta * L) / pdf;
+        }
+    }
+    pb.radiance[0 * cap + p] = L.x; pb.radiance[1 * cap + p] = L.y; pb.radiance[2 * cap + p] = L.z;
+}
+
+// per pixel: fixed-order f64 sum over this pass's samples, then one fp32 add into the accumulator
+__global__ __launch_bounds__(256) void k_accumulate(const double* __restrict__ radiance, uint32_t cap, uint32_t npix, uint32_t samples, float* __restrict__ accum) {
+    const uint32_t px = blockIdx.x * blockDim.x + threadIdx.x;
+    if (px >= npix) return;
+    double r = 0.0, g = 0.0, b = 0.0;
+    for (uint32_t s = 0; s < samples; ++s) {
+        size_t p = (size_t)s * npix + px;
+        r += radiance[0 * (size_t)cap + p]; g += radiance[1 * (size_t)cap + p]; b += radiance[2 * (size_t)cap + p];
+    }
+    accum[3 * (size_t)px + 0] += (float)r; accum[3 * (size_t)px + 1] += (float)g; accum[3 * (size_t)px + 2] += (float)b;
+}
+
+RT_DEV float aces_channel(float x) {  // main.rs:913-921
+    float v = (x * (2.51f * x + 0.03f)) / (x * (2.43f * x + 0.59f) + 0.14f);
+    return fminf(fmaxf(v, 0.0f), 1.0f);  // glam clamp = max(min).min(max): NaN -> 0
+}
+__global__ __launch_bounds__(256) void k_resolve(const float* __restrict__ accum, uint32_t n3, float inv_unused, uint32_t spp, int tonemap, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n3) return;
+    float c = accum[i] / (float)spp;  // main.rs:1009
+    if (tonemap) c = aces_channel(c);
+    if (c != c) c = 0.0f;             // image.rs:48-56
+    out[i] = c;
+}
+
+__global__ void k_aos_to_soa(const double* __restrict__ aos, uint32_t n, double* __restrict__ soa, uint32_t cap) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) soa[(size_t)c * cap + i] = aos[(size_t)i * 7 + c];
+}
+__global__ void k_soa_to_aos(const double* __restrict__ soa, uint32_t n, uint32_t cap, double* __restrict__ aos) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) aos[(size_t)i * 7 + c] = soa[(size_t)c * cap + i];
+}
+__global__ void k_iota(uint32_t* q, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) q[i] = i;
+}
+__global__ void k_set_u32(uint32_t* p, uint32_t v) { *p = v; }
+__global__ void k_div_sqrt(uint32_t n, const double* a, const double* b, double* q, double* s) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { q[i] = a[i] / b[i]; s[i] = __builtin_sqrt(a[i]); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side of the ABI
+// ------------------------------------------------------------------------------------------------
+struct rt_context {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+};
+
+struct Workspace {
+    PathBuffers pb{};
+    uint32_t* queue[2] = {nullptr, nullptr};
+    uint32_t* shadow_queue = nullptr;
+    uint32_t* counts = nullptr;  // [0],[1]: path queue counts; [2]: shadow count
+    unsigned long long* stats = nullptr;  // rays, box, tri, sph
+    uint32_t* in_pixel = nullptr; uint32_t* in_sample = nullptr;
+    uint32_t cap = 0; int32_t depth = 0;
+    std::vector<void*> allocs;
+};
+
+struct rt_scene {
+    rt_context* ctx;
+    void* dblob = nullptr;
+    uint8_t* d_mat_uses_uv = nullptr;
+    SceneDev dev{};
+    rt_blob_header hdr{};
+    std::vector<rt_prim> host_prims;
+    Workspace ws;
+};
+
+static void ws_free(Workspace& ws) {
+    for (void* p : ws.allocs) (void)hipFree(p);
+    ws = Workspace();
+}
+template <class T> static int ws_alloc(Workspace& ws, T*& out, size_t count) {
+    void* p = nullptr;
+    HIP_OK(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    ws.allocs.push_back(p);
+    out = (T*)p;
+    return RT_OK;
+}
+static int ws_ensure(rt_scene* sc, uint32_t cap, int32_t depth) {
+    Workspace& ws = sc->ws;
+    if (ws.cap >= cap && ws.depth >= depth) return RT_OK;
+    ws_free(ws);
+    cap = (cap + 255u) & ~255u;
+    int rc;
+#define WS(ptr, count) if ((rc = ws_alloc(ws, ptr, (size_t)(count))) != RT_OK) { ws_free(ws); return rc; }
+    WS(ws.pb.rays, 7 * (size_t)cap) WS(ws.pb.shadow_rays, 7 * (size_t)cap)
+    WS(ws.pb.hit_prim, cap) WS(ws.pb.hit_inst, cap) WS(ws.pb.hit_t, cap) WS(ws.pb.shadow_prim, cap)
+    WS(ws.pb.path_pixel, cap) WS(ws.pb.path_sample, cap) WS(ws.pb.nb, cap)
+    WS(ws.pb.terminal, 3 * (size_t)cap) WS(ws.pb.radiance, 3 * (size_t)cap)
+    WS(ws.pb.records, (size_t)std::max(depth, 1) * REC_FIELDS * cap)
+    WS(ws.queue[0], cap) WS(ws.queue[1], cap) WS(ws.shadow_queue, cap) WS(ws.counts, 4) WS(ws.stats, 4)
+    WS(ws.in_pixel, cap) WS(ws.in_sample, cap)
+#undef WS
+    ws.pb.cap = cap; ws.cap = cap; ws.depth = depth;
+    return RT_OK;
+}
+
+static inline dim3 grid_for(uint32_t n) { return dim3((n + 255u) / 256u); }
+
+struct EventTimer {
+    struct Span { hipEvent_t a, b; int cat; };
+    std::vector<Span> spans;
+    hipStream_t s;
+    bool enabled;
+    explicit EventTimer(hipStream_t st, bool en) : s(st), enabled(en) {}
+    void begin(int cat) {
+        if (!enabled) return;
+        Span sp; sp.cat = cat;
+        (void)hipEventCreate(&sp.a); (void)hipEventCreate(&sp.b);
+        (void)hipEventRecord(sp.a, s);
+        spans.push_back(sp);
+    }
+    void end() { if (enabled) (void)hipEventRecord(spans.back().b, s); }
+    void collect(double* ms_by_cat, int ncat, uint64_t* count_by_cat) {
+        for (auto& sp : spans) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, sp.a, sp.b);
+            if (sp.cat < ncat) { ms_by_cat[sp.cat] += ms; count_by_cat[sp.cat]++; }
+            (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b);
+        }
+        spans.clear();
+    }
+};
+enum { CAT_TRACE = 0, CAT_SHADE = 1, CAT_OTHER = 2, CAT_N = 3 };
+
+static void launch_trace(rt_scene* sc, bool count, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_bound, const double* rays, double t_min,
+                         double t_max, uint32_t* out_prim, uint32_t* out_inst, double* out_t) {
+    hipStream_t st = sc->ctx->stream;
+    if (n_bound == 0) return;
+    if (count) hipLaunchKernelGGL(k_trace<true>, grid_for(n_bound), dim3(256), 0, st, sc->dev, queue, n_ptr, n_bound, rays, sc->ws.cap, t_min, t_max, out_prim, out_inst, out_t, sc->ws.stats);
+    else hipLaunchKernelGGL(k_trace<false>, grid_for(n_bound), dim3(256), 0, st, sc->dev, queue, n_ptr, n_bound, rays, sc->ws.cap, t_min, t_max, out_prim, out_inst, out_t, sc->ws.stats);
+}
+
+// Runs the wavefront loop for n paths whose (pixel, sample) come either from explicit device lists
+// (ws.in_pixel / ws.in_sample) or from the frame formula; leaves per-path radiance in ws.pb.radiance.
+static int run_paths(rt_scene* sc, uint32_t n, bool explicit_lists, uint32_t width, uint32_t height, uint32_t sample0, int32_t max_depth,
+                     int32_t integrator, uint64_t seed, bool count_tests, EventTimer& tm, uint64_t& launches) {
+    Workspace& ws = sc->ws;
+    hipStream_t st = sc->ctx->stream;
+    const uint32_t npix = width * height;
+    tm.begin(CAT_OTHER);
+    hipLaunchKernelGGL(k_raygen, grid_for(n), dim3(256), 0, st, sc->dev.camera, width, height, n, sample0, npix,
+                       explicit_lists ? ws.in_pixel : nullptr, explicit_lists ? ws.in_sample : nullptr, seed, ws.pb.rays, ws.cap, ws.pb.path_pixel,
+                       ws.pb.path_sample, ws.pb.nb);
+    hipLaunchKernelGGL(k_iota, grid_for(n), dim3(256), 0, st, ws.queue[0], n);
+    hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, ws.counts + 0, n);
+    tm.end();
+    launches += 3;
+    int cur = 0;
+    for (int32_t bounce = 0; bounce < max_depth; ++bounce) {
+        const int nxt = cur ^ 1;
+        HIP_OK(hipMemsetAsync(ws.counts + nxt, 0, sizeof(uint32_t), st));
+        HIP_OK(hipMemsetAsync(ws.counts + 2, 0, sizeof(uint32_t), st));
+        tm.begin(CAT_TRACE);
+        launch_trace(sc, count_tests, ws.queue[cur], ws.counts + cur, n, ws.pb.rays, 0.001, 100000.0, ws.pb.hit_prim, ws.pb.hit_inst, ws.pb.hit_t);  // integrator.rs:38
+        tm.end();
+        tm.begin(CAT_SHADE);
+        hipLaunchKernelGGL(k_shade, grid_for(n), dim3(256), 0, st, sc->dev, ws.pb, ws.queue[cur], ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
+                           seed, ws.queue[nxt], ws.counts + nxt, ws.shadow_queue, ws.counts + 2);
+        tm.end();
+        launches += 2;
+        if (integrator == RT_INT_MIS && sc->dev.n_lights > 0) {
+            tm.begin(CAT_TRACE);
+            launch_trace(sc, count_tests, ws.shadow_queue, ws.counts + 2, n, ws.pb.shadow_rays, 0.001, 10000.0, ws.pb.shadow_prim, nullptr,
+                         ws.pb.records + ((size_t)bounce * REC_FIELDS + REC_T_SHADOW) * ws.cap);  // integrator.rs:82
+            tm.end();
+            launches += 1;
+        }
+        cur = nxt;
+    }
+    tm.begin(CAT_OTHER);
+    hipLaunchKernelGGL(k_unwind, grid_for(n), dim3(256), 0, st, ws.pb, n);
+    tm.end();
+    launches += 1;
+    HIP_OK(hipGetLastError());
+    return RT_OK;
+}
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_err.c_str(); }
+
+int rt_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, hipGetErrorString(e));
+    return n;
+}
+
+int rt_context_create(int device, void* stream, rt_context** out) {
+    if (!out) return fail(RT_ERR_BAD_ARG, "rt_context_create: out is NULL");
+    int n = 0;
+    HIP_OK(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(RT_ERR_BAD_ARG, "rt_context_create: no such device");
+    HIP_OK(hipSetDevice(device));
+    rt_context* c = new (std::nothrow) rt_context();
+    if (!c) return fail(RT_ERR_OOM, "rt_context_create: host allocation failed");
+    c->device = device;
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return fail(RT_ERR_HIP, hipGetErrorString(e)); }
+        c->own_stream = true;
+    }
+    *out = c;
+    return RT_OK;
+}
+int rt_context_destroy(rt_context* ctx) {
+    if (!ctx) return RT_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RT_OK;
+}
+int rt_context_synchronize(rt_context* ctx) {
+    if (!ctx) return fail(RT_ERR_BAD_ARG, "null context");
+    HIP_OK(hipSetDevice(ctx->device));
+    HIP_OK(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+static bool range_ok(uint64_t off, uint64_t count, uint64_t elem, uint64_t total) {
+    return off % 16 == 0 && off <= total && count * elem <= total - off;
+}
+
+int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene** out) {
+    if (!ctx || !blob || !out) return fail(RT_ERR_BAD_ARG, "rt_scene_upload: null argument");
+    if (nbytes < sizeof(rt_blob_header)) return fail(RT_ERR_BAD_BLOB, "blob smaller than its header");
+    rt_blob_header h;
+    memcpy(&h, blob, sizeof h);
+    if (h.magic != RT_BLOB_MAGIC || h.version != RT_BLOB_VERSION) return fail(RT_ERR_BAD_BLOB, "bad blob magic/version");
+    if (h.total_bytes != nbytes) return fail(RT_ERR_BAD_BLOB, "blob size mismatch");
+    // operand-shape checks: every index the kernels follow is validated here, on the host
+    if (!range_ok(h.off_nodes, h.n_nodes, sizeof(rt_node), nbytes) || !range_ok(h.off_prims, h.n_prims, sizeof(rt_prim), nbytes) ||
+        !range_ok(h.off_tri_verts, h.n_tris, sizeof(rt_tri_verts), nbytes) || !range_ok(h.off_tri_attrs, h.n_tris, sizeof(rt_tri_attrs), nbytes) ||
+        !range_ok(h.off_spheres, h.n_spheres, sizeof(rt_sphere), nbytes) || !range_ok(h.off_moving_spheres, h.n_moving_spheres, sizeof(rt_moving_sphere), nbytes) ||
+        !range_ok(h.off_rects, h.n_rects, sizeof(rt_aarect), nbytes) || !range_ok(h.off_xforms, h.n_xforms, sizeof(rt_xform), nbytes) ||
+        !range_ok(h.off_materials, h.n_materials, sizeof(rt_material), nbytes) || !range_ok(h.off_textures, h.n_textures, sizeof(rt_texture), nbytes) ||
+        !range_ok(h.off_texels, h.n_texel_bytes, 1, nbytes) || !range_ok(h.off_lights, h.n_lights, sizeof(rt_light), nbytes))
+        return fail(RT_ERR_BAD_BLOB, "table offset/size out of range");
+    const uint8_t* b = (const uint8_t*)blob;
+    const rt_node* nodes = (const rt_node*)(b + h.off_nodes);
+    const rt_prim* prims = (const rt_prim*)(b + h.off_prims);
+    const rt_material* mats = (const rt_material*)(b + h.off_materials);
+    const rt_texture* tex = (const rt_texture*)(b + h.off_textures);
+    if (h.root_node > h.root_end || h.root_end > h.n_nodes) return fail(RT_ERR_BAD_BLOB, "root range out of bounds");
+    for (uint32_t i = 0; i < h.n_nodes; ++i) {
+        if (nodes[i].skip <= i || nodes[i].skip > h.n_nodes) return fail(RT_ERR_BAD_BLOB, "node skip link not strictly forward / out of range");
+        if ((nodes[i].prim0 != RT_NONE && nodes[i].prim0 >= h.n_prims) || (nodes[i].prim1 != RT_NONE && nodes[i].prim1 >= h.n_prims))
+            return fail(RT_ERR_BAD_BLOB, "node primitive index out of range");
+        if (nodes[i].prim0 == RT_NONE && nodes[i].prim1 != RT_NONE) return fail(RT_ERR_BAD_BLOB, "node with prim1 but no prim0");
+    }
+    for (uint32_t i = 0; i < h.n_prims; ++i) {
+        const rt_prim& p = prims[i];
+        uint32_t lim = p.kind == RT_PRIM_TRIANGLE ? h.n_tris : p.kind == RT_PRIM_SPHERE ? h.n_spheres : p.kind == RT_PRIM_MOVING_SPHERE ? h.n_moving_spheres
+                     : p.kind == RT_PRIM_AARECT ? h.n_rects : p.kind == RT_PRIM_INSTANCE ? h.n_nodes : 0;
+        if (p.kind > RT_PRIM_INSTANCE || p.index >= lim) return fail(RT_ERR_BAD_BLOB, "primitive kind/index out of range");
+        if (p.xform != RT_NONE && p.xform >= h.n_xforms) return fail(RT_ERR_BAD_BLOB, "primitive xform out of range");
+        if (p.kind == RT_PRIM_INSTANCE) {
+            if (p.sub_end <= p.index || p.sub_end > h.n_nodes || p.index < h.root_end) return fail(RT_ERR_BAD_BLOB, "instance sub-array out of range");
+            for (uint32_t k = p.index; k < p.sub_end; ++k) {
+                if (nodes[k].skip > p.sub_end) return fail(RT_ERR_BAD_BLOB, "instance skip link leaves its sub-array");
+                for (uint32_t q : {nodes[k].prim0, nodes[k].prim1})
+                    if (q != RT_NONE && (prims[q].kind == RT_PRIM_INSTANCE || prims[q].xform != RT_NONE))
+                        return fail(RT_ERR_UNSUPPORTED, "nested instance / transformed primitive inside an instance");
+            }
+        } else if (p.material >= h.n_materials) return fail(RT_ERR_BAD_BLOB, "primitive material out of range");
+    }
+    for (uint32_t k = h.root_node; k < h.root_end; ++k)
+        if (nodes[k].skip > h.root_end) return fail(RT_ERR_BAD_BLOB, "scene-level skip link leaves the scene array");
+    std::vector<uint8_t> uses_uv(std::max<uint32_t>(h.n_materials, 1), 0);
+    for (uint32_t i = 0; i < h.n_textures; ++i) {
+        if (tex[i].kind > RT_TEX_IMAGE) return fail(RT_ERR_BAD_BLOB, "texture kind");
+        if (tex[i].kind == RT_TEX_CHECKER && (tex[i].a >= h.n_textures || tex[i].b >= h.n_textures)) return fail(RT_ERR_BAD_BLOB, "checker child out of range");
+        if (tex[i].kind == RT_TEX_IMAGE && (tex[i].b == 0 || tex[i].c == 0 || (uint64_t)tex[i].a + (uint64_t)tex[i].b * tex[i].c * 3 > h.n_texel_bytes))
+            return fail(RT_ERR_BAD_BLOB, "image texture outside the texel pool");
+    }
+    for (uint32_t i = 0; i < h.n_materials; ++i) {
+        if (mats[i].kind > RT_MAT_DIFFUSE_LIGHT) return fail(RT_ERR_BAD_BLOB, "material kind");
+        bool needs_tex = mats[i].kind == RT_MAT_LAMBERTIAN || mats[i].kind == RT_MAT_DIFFUSE_LIGHT;
+        if (needs_tex && mats[i].texture >= h.n_textures) return fail(RT_ERR_BAD_BLOB, "material texture out of range");
+        if (needs_tex) {  // does the texture tree reach an image? (bounded walk; checker trees deeper than 8 are rejected)
+            std::vector<std::pair<uint32_t, int>> stack{{mats[i].texture, 0}};
+            while (!stack.empty()) {
+                auto [t, dpt] = stack.back(); stack.pop_back();
+                if (tex[t].kind == RT_TEX_IMAGE) uses_uv[i] = 1;
+                else if (tex[t].kind == RT_TEX_CHECKER) {
+                    if (dpt >= 8) return fail(RT_ERR_UNSUPPORTED, "checker texture nesting deeper than 8");
+                    stack.push_back({tex[t].a, dpt + 1}); stack.push_back({tex[t].b, dpt + 1});
+                }
+            }
+        }
+    }
+    const rt_light* lights = (const rt_light*)(b + h.off_lights);
+    for (uint32_t i = 0; i < h.n_lights; ++i)
+        if (lights[i].material >= h.n_materials) return fail(RT_ERR_BAD_BLOB, "light material out of range");
+
+    HIP_OK(hipSetDevice(ctx->device));
+    rt_scene* sc = new (std::nothrow) rt_scene();
+    if (!sc) return fail(RT_ERR_OOM, "host allocation failed");
+    sc->ctx = ctx; sc->hdr = h;
+    sc->host_prims.assign(prims, prims + h.n_prims);
+    hipError_t e = hipMalloc(&sc->dblob, nbytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&sc->d_mat_uses_uv, uses_uv.size());
+    if (e == hipSuccess) e = hipMemcpy(sc->dblob, blob, nbytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(sc->d_mat_uses_uv, uses_uv.data(), uses_uv.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (sc->dblob) (void)hipFree(sc->dblob);
+        if (sc->d_mat_uses_uv) (void)hipFree(sc->d_mat_uses_uv);
+        delete sc;
+        return fail(e == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, hipGetErrorString(e));
+    }
+    const uint8_t* d = (const uint8_t*)sc->dblob;
+    SceneDev& v = sc->dev;
+    v.nodes = (const rt_node*)(d + h.off_nodes); v.prims = (const rt_prim*)(d + h.off_prims);
+    v.tri_verts = (const rt_tri_verts*)(d + h.off_tri_verts); v.tri_attrs = (const rt_tri_attrs*)(d + h.off_tri_attrs);
+    v.spheres = (const rt_sphere*)(d + h.off_spheres); v.moving = (const rt_moving_sphere*)(d + h.off_moving_spheres);
+    v.rects = (const rt_aarect*)(d + h.off_rects); v.xforms = (const rt_xform*)(d + h.off_xforms);
+    v.materials = (const rt_material*)(d + h.off_materials); v.textures = (const rt_texture*)(d + h.off_textures);
+    v.texels = d + h.off_texels; v.lights = (const rt_light*)(d + h.off_lights);
+    v.mat_uses_uv = sc->d_mat_uses_uv;
+    v.camera = h.camera; v.n_lights = h.n_lights; v.root_node = h.root_node; v.root_end = h.root_end; v.background = h.background;
+    *out = sc;
+    return RT_OK;
+}
+
+int rt_scene_destroy(rt_scene* sc) {
+    if (!sc) return RT_OK;
+    (void)hipSetDevice(sc->ctx->device);
+    (void)hipStreamSynchronize(sc->ctx->stream);
+    ws_free(sc->ws);
+    (void)hipFree(sc->dblob);
+    (void)hipFree(sc->d_mat_uses_uv);
+    delete sc;
+    return RT_OK;
+}
+
+int rt_trace_closest_device(rt_scene* sc, uint32_t n, const double* rays_dev, double t_min, double t_max, uint32_t* prim_id_dev, double* t_dev) {
+    if (!sc || (n && (!rays_dev || !prim_id_dev || !t_dev))) return fail(RT_ERR_BAD_ARG, "rt_trace_closest_device: null argument");
+    if (n == 0) return RT_OK;
+    HIP_OK(hipSetDevice(sc->ctx->device));
+    int rc = ws_ensure(sc, n, sc->ws.depth > 0 ? sc->ws.depth : 1);
+    if (rc != RT_OK) return rc;
+    hipStream_t st = sc->ctx->stream;
+    hipLaunchKernelGGL(k_aos_to_soa, grid_for(n), dim3(256), 0, st, rays_dev, n, sc->ws.pb.rays, sc->ws.cap);
+    launch_trace(sc, false, nullptr, nullptr, n, sc->ws.pb.rays, t_min, t_max, prim_id_dev, nullptr, t_dev);
+    HIP_OK(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_trace_closest(rt_scene* sc, uint32_t n, const double* rays, double t_min, double t_max, uint32_t* prim_id, uint32_t* inst_id, double* t,
+                     uint64_t* counters) {
+    if (!sc || (n && (!rays || !prim_id || !t))) return fail(RT_ERR_BAD_ARG, "rt_trace_closest: null argument");
+    if (n == 0) { if (counters) counters[0] = counters[1] = counters[2] = 0; return RT_OK; }
+    HIP_OK(hipSetDevice(sc->ctx->device));
+    int rc = ws_ensure(sc, n, sc->ws.depth > 0 ? sc->ws.depth : 1);
+    if (rc != RT_OK) return rc;
+    Workspace& ws = sc->ws;
+    hipStream_t st = sc->ctx->stream;
+    std::vector<double> soa(7 * (size_t)ws.cap, 0.0);
+    for (uint32_t i = 0; i < n; ++i)
+        for (int c = 0; c < 7; ++c) soa[(size_t)c * ws.cap + i] = rays[(size_t)i * 7 + c];
+    HIP_OK(hipMemcpyAsync(ws.pb.rays, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemsetAsync(ws.stats, 0, 4 * sizeof(unsigned long long), st));
+    launch_trace(sc, counters != nullptr, nullptr, nullptr, n, ws.pb.rays, t_min, t_max, ws.pb.hit_prim, ws.pb.hit_inst, ws.pb.hit_t);
+    HIP_OK(hipGetLastError());
+    std::vector<uint32_t> hp(n), hi(n);
+    unsigned long long st4[4];
+    HIP_OK(hipMemcpyAsync(hp.data(), ws.pb.hit_prim, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(hi.data(), ws.pb.hit_inst, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(t, ws.pb.hit_t, n * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(st4, ws.stats, sizeof st4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    for (uint32_t i = 0; i < n; ++i) {
+        if (hp[i] == RT_NONE) { prim_id[i] = RT_NONE; if (inst_id) inst_id[i] = RT_NONE; t[i] = 0.0; continue; }
+        const rt_prim& p = sc->host_prims[hp[i]];
+        prim_id[i] = p.object_id;
+        if (inst_id) inst_id[i] = hi[i] != RT_NONE ? sc->host_prims[hi[i]].inst_id : p.inst_id;
+    }
+    if (counters) { counters[0] = st4[1]; counters[1] = st4[2]; counters[2] = st4[3]; }
+    return RT_OK;
+}
+
+int rt_primary_rays(rt_scene* sc, uint32_t width, uint32_t height, uint32_t sample, uint64_t seed, double* rays) {
+    if (!sc || !rays || width < 2 || height < 2) return fail(RT_ERR_BAD_ARG, "rt_primary_rays: bad argument");
+    const uint64_t n64 = (uint64_t)width * height;
+    if (n64 > 0x7FFFFFFFull) return fail(RT_ERR_BAD_ARG, "rt_primary_rays: frame too large");
+    const uint32_t n = (uint32_t)n64;
+    HIP_OK(hipSetDevice(sc->ctx->device));
+    int rc = ws_ensure(sc, n, sc->ws.depth > 0 ? sc->ws.depth : 1);
+    if (rc != RT_OK) return rc;
+    Workspace& ws = sc->ws;
+    hipStream_t st = sc->ctx->stream;
+    hipLaunchKernelGGL(k_raygen, grid_for(n), dim3(256), 0, st, sc->dev.camera, width, height, n, sample, n, (const uint32_t*)nullptr, (const uint32_t*)nullptr, seed,
+                       ws.pb.rays, ws.cap, ws.pb.path_pixel, ws.pb.path_sample, (uint32_t*)nullptr);
+    double* aos = nullptr;
+    HIP_OK(hipMalloc((void**)&aos, (size_t)n * 7 * sizeof(double)));
+    hipLaunchKernelGGL(k_soa_to_aos, grid_for(n), dim3(256), 0, st, ws.pb.rays, n, ws.cap, aos);
+    hipError_t e = hipMemcpyAsync(rays, aos, (size_t)n * 7 * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(aos);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, hipGetErrorString(e));
+    return RT_OK;
+}
+
+static int check_params(const rt_render_params* p) {
+    if (!p) return fail(RT_ERR_BAD_ARG, "null params");
+    if (p->width < 2 || p->height < 2) return fail(RT_ERR_BAD_ARG, "width/height must be >= 2 (u = (x+xi)/(width-1), main.rs:996)");
+    if ((uint64_t)p->width * p->height > (1ull << 28)) return fail(RT_ERR_BAD_ARG, "frame too large");
+    if (p->spp_end < p->spp_begin) return fail(RT_ERR_BAD_ARG, "spp_end < spp_begin");
+    if (p->max_depth < 0 || p->max_depth > 4096) return fail(RT_ERR_BAD_ARG, "max_depth out of range");
+    if (p->integrator < RT_INT_MIS || p->integrator > RT_INT_UNIFORM) return fail(RT_ERR_BAD_ARG, "unknown integrator");
+    return RT_OK;
+}
+
+int rt_accum_zero(rt_context* ctx, float* accum_dev, uint32_t width, uint32_t height) {
+    if (!ctx || !accum_dev) return fail(RT_ERR_BAD_ARG, "rt_accum_zero: null argument");
+    HIP_OK(hipSetDevice(ctx->device));
+    HIP_OK(hipMemsetAsync(accum_dev, 0, (size_t)width * height * 3 * sizeof(float), ctx->stream));
+    return RT_OK;
+}
+
+int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stats* stats) {
+    if (!sc || !accum_dev) return fail(RT_ERR_BAD_ARG, "rt_render: null argument");
+    int rc = check_params(p);
+    if (rc != RT_OK) return rc;
+    HIP_OK(hipSetDevice(sc->ctx->device));
+    const uint32_t npix = p->width * p->height;
+    const uint32_t spp = p->spp_end - p->spp_begin;
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (spp == 0 || p->max_depth == 0) {  // depth <= 0: every sample returns 0 (integrator.rs:33-35)
+        if (stats) stats->paths = (uint64_t)npix * spp;
+        HIP_OK(hipStreamSynchronize(sc->ctx->stream));
+        return RT_OK;
+    }
+    // paths in flight: bounded by ~4M paths and ~12 GiB of bounce records
+    uint32_t spass = p->samples_per_pass;
+    if (spass == 0) {
+        uint64_t by_paths = std::max<uint64_t>(1, (4ull << 20) / npix);
+        uint64_t by_mem = std::max<uint64_t>(1, (12ull << 30) / ((uint64_t)npix * ((uint64_t)p->max_depth * REC_FIELDS * 8 + 256)));
+        spass = (uint32_t)std::min<uint64_t>(std::min(by_paths, by_mem), 64);
+    }
+    spass = std::min(spass, spp);
+    if ((uint64_t)npix * spass > 0x7FFFFF00ull) return fail(RT_ERR_BAD_ARG, "samples_per_pass * pixels too large");
+    rc = ws_ensure(sc, npix * spass, p->max_depth);
+    if (rc != RT_OK) return rc;
+    Workspace& ws = sc->ws;
+    hipStream_t st = sc->ctx->stream;
+    const bool count_tests = (p->flags & RT_RENDER_COUNT_TESTS) != 0;
+    HIP_OK(hipMemsetAsync(ws.stats, 0, 4 * sizeof(unsigned long long), st));
+    EventTimer tm(st, stats != nullptr);
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    HIP_OK(hipEventRecord(e0, st));
+    uint64_t launches = 0;
+    for (uint32_t s0 = p->spp_begin; s0 < p->spp_end; s0 += spass) {
+        const uint32_t ns = std::min(spass, p->spp_end - s0);
+        const uint32_t n = npix * ns;
+        rc = run_paths(sc, n, false, p->width, p->height, s0, p->max_depth, p->integrator, p->seed, count_tests, tm, launches);
+        if (rc != RT_OK) return rc;
+        tm.begin(CAT_OTHER);
+        hipLaunchKernelGGL(k_accumulate, grid_for(npix), dim3(256), 0, st, ws.pb.radiance, ws.cap, npix, ns, accum_dev);
+        tm.end();
+        launches += 1;
+    }
+    HIP_OK(hipEventRecord(e1, st));
+    unsigned long long st4[4];
+    HIP_OK(hipMemcpyAsync(st4, ws.stats, sizeof st4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    HIP_OK(hipGetLastError());
+    if (stats) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        double by_cat[CAT_N] = {0, 0, 0}; uint64_t n_by_cat[CAT_N] = {0, 0, 0};
+        tm.collect(by_cat, CAT_N, n_by_cat);
+        stats->rays = st4[0]; stats->box_tests = st4[1]; stats->tri_tests = st4[2]; stats->sphere_tests = st4[3];
+        stats->paths = (uint64_t)npix * spp; stats->launches = launches;
+        stats->ms_total = ms; stats->ms_trace = by_cat[CAT_TRACE]; stats->ms_shade = by_cat[CAT_SHADE]; stats->ms_other = by_cat[CAT_OTHER];
+        stats->trace_launches = n_by_cat[CAT_TRACE];
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return RT_OK;
+}
+
+int rt_render_host(rt_scene* sc, const rt_render_params* p, float* accum_host, rt_stats* stats) {
+    if (!sc || !accum_host) return fail(RT_ERR_BAD_ARG, "rt_render_host: null argument");
+    int rc = check_params(p);
+    if (rc != RT_OK) return rc;
+    HIP_OK(hipSetDevice(sc->ctx->device));
+    const size_t bytes = (size_t)p->width * p->height * 3 * sizeof(float);
+    float* d = nullptr;
+    HIP_OK(hipMalloc((void**)&d, bytes));
+    hipError_t e = hipMemsetAsync(d, 0, bytes, sc->ctx->stream);
+    if (e == hipSuccess) {
+        rc = rt_render(sc, p, d, stats);
+        if (rc == RT_OK) e = hipMemcpy(accum_host, d, bytes, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d);
+    if (rc != RT_OK) return rc;
+    if (e != hipSuccess) return fail(RT_ERR_HIP, hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_resolve(rt_context* ctx, const float* accum_dev, uint32_t width, uint32_t height, uint32_t spp, int tonemap, float* out_dev) {
+    if (!ctx || !accum_dev || !out_dev || spp == 0) return fail(RT_ERR_BAD_ARG, "rt_resolve: bad argument");
+    HIP_OK(hipSetDevice(ctx->device));
+    const uint32_t n3 = width * height * 3;
+    hipLaunchKernelGGL(k_resolve, grid_for(n3), dim3(256), 0, ctx->stream, accum_dev, n3, 0.f, spp, tonemap, out_dev);
+    HIP_OK(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_resolve_host(const float* accum_host, uint32_t width, uint32_t height, uint32_t spp, int tonemap, float* out_host) {
+    if (!accum_host || !out_host || spp == 0) return fail(RT_ERR_BAD_ARG, "rt_resolve_host: bad argument");
+    const size_t bytes = (size_t)width * height * 3 * sizeof(float);
+    float *a = nullptr, *o = nullptr;
+    HIP_OK(hipMalloc((void**)&a, bytes));
+    hipError_t e = hipMalloc((void**)&o, bytes);
+    if (e == hipSuccess) e = hipMemcpy(a, accum_host, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const uint32_t n3 = width * height * 3;
+        hipLaunchKernelGGL(k_resolve, grid_for(n3), dim3(256), 0, 0, a, n3, 0.f, spp, tonemap, o);
+        e = hipMemcpy(out_host, o, bytes, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(a); (void)hipFree(o);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_sample_radiance(rt_scene* sc, uint32_t width, uint32_t height, uint32_t n, const uint32_t* pixel_index, const uint32_t* sample_index,
+                       int32_t max_depth, int32_t integrator, uint64_t seed, double* out_rgb) {
+    if (!sc || (n && (!pixel_index || !sample_index || !out_rgb))) return fail(RT_ERR_BAD_ARG, "rt_sample_radiance: null argument");
+    rt_render_params p{}; p.width = width; p.height = height; p.max_depth = max_depth; p.integrator = integrator;
+    int rc = check_params(&p);
+    if (rc != RT_OK) return rc;
+    if (n == 0) return RT_OK;
+    for (uint32_t i = 0; i < n; ++i)
+        if (pixel_index[i] >= width * height) return fail(RT_ERR_BAD_ARG, "pixel index out of range");
+    HIP_OK(hipSetDevice(sc->ctx->device));
+    if (max_depth == 0) { memset(out_rgb, 0, (size_t)n * 3 * sizeof(double)); return RT_OK; }
+    rc = ws_ensure(sc, n, max_depth);
+    if (rc != RT_OK) return rc;
+    Workspace& ws = sc->ws;
+    hipStream_t st = sc->ctx->stream;
+    HIP_OK(hipMemcpyAsync(ws.in_pixel, pixel_index, n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(ws.in_sample, sample_index, n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    EventTimer tm(st, false);
+    uint64_t launches = 0;
+    rc = run_paths(sc, n, true, width, height, 0, max_depth, integrator, seed, false, tm, launches);
+    if (rc != RT_OK) return rc;
+    std::vector<double> rad(3 * (size_t)ws.cap);
+    HIP_OK(hipMemcpyAsync(rad.data(), ws.pb.radiance, rad.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    for (uint32_t i = 0; i < n; ++i)
+        for (int c = 0; c < 3; ++c) out_rgb[(size_t)i * 3 + c] = rad[(size_t)c * ws.cap + i];
+    return RT_OK;
+}
+
+int rt_ieee_div_sqrt(rt_context* ctx, uint32_t n, const double* a, const double* b, double* q, double* s) {
+    if (!ctx || (n && (!a || !b || !q || !s))) return fail(RT_ERR_BAD_ARG, "rt_ieee_div_sqrt: null argument");
+    if (n == 0) return RT_OK;
+    HIP_OK(hipSetDevice(ctx->device));
+    double* d = nullptr;
+    const size_t bytes = (size_t)n * sizeof(double);
+    HIP_OK(hipMalloc((void**)&d, 4 * bytes));
+    hipError_t e = hipMemcpy(d, a, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + n, b, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_div_sqrt, grid_for(n), dim3(256), 0, ctx->stream, n, d, d + n, d + 2 * (size_t)n, d + 3 * (size_t)n);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(q, d + 2 * (size_t)n, bytes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(s, d + 3 * (size_t)n, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, hipGetErrorString(e));
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,299 @@
+// Device view of the flattened scene + primitive intersection / hit-record / material / PDF
+// device functions.  Each function cites the reference lines it implements (paths relative to
+// /root/reference).  f64 throughout: on CDNA4 a wave64 f64 VALU op issues at the same rate as an
+// unpacked f32 one, so the reference's f64 semantics are kept rather than down-converted.
+#pragma once
+#include "../../include/rt_abi.h"
+#include "rt_math.h"
+
+namespace rt {
+
+// Pointers into the resident blob.  Node / primitive / geometry tables are read through the
+// constant address space from wave-uniform indices, which makes hipcc emit scalar loads
+// (s_load_dwordx*): one fetch per wave instead of 64 per-lane fetches.
+#define RT_CONST __attribute__((address_space(4)))
+template <class T> using cptr = const RT_CONST T*;
+template <class T> RT_DEV cptr<T> as_const(const T* p) { return (cptr<T>)(uintptr_t)p; }
+
+struct SceneDev {
+    const rt_node* nodes;
+    const rt_prim* prims;
+    const rt_tri_verts* tri_verts;
+    const rt_tri_attrs* tri_attrs;
+    const rt_sphere* spheres;
+    const rt_moving_sphere* moving;
+    const rt_aarect* rects;
+    const rt_xform* xforms;
+    const rt_material* materials;
+    const rt_texture* textures;
+    const uint8_t* texels;
+    const rt_light* lights;
+    const uint8_t* mat_uses_uv;
+    rt_camera camera;
+    uint32_t n_lights, root_node, root_end, background;
+};
+
+// ---- bounding_box.rs:27-46, literal: three independent per-axis tests against the ORIGINAL
+// [t_min, t_max] (the `let` at lines 37-38 shadows inside the loop body).  inv = 1/dir is hoisted
+// per ray: the same IEEE division the reference performs per test.
+RT_DEV bool box_axis(double bmin, double bmax, double o, double inv, double t_min, double t_max) {
+    double t0 = (bmin - o) * inv;
+    double t1 = (bmax - o) * inv;
+    bool sw = t1 < t0;
+    double a = sw ? t1 : t0, b = sw ? t0 : t1;
+    double lo = a > t_min ? a : t_min;
+    double hi = b < t_max ? b : t_max;
+    return !(hi < lo);
+}
+
+// ---- primitive tests: return true and t when the reference's `hit` returns Some --------------
+// mesh.rs:48-81 (Moller-Trumbore, two-sided, exact statement order)
+RT_DEV bool tri_hit(d3 v0, d3 v1, d3 v2, d3 o, d3 d, double t_min, double t_max, double& t_out, double& u_out, double& v_out) {
+    d3 edge1 = v1 - v0, edge2 = v2 - v0;
+    d3 h = cross(d, edge2);
+    double det = dot(edge1, h);
+    if (det > -F64_EPS && det < F64_EPS) return false;
+    double det_inv = 1.0 / det;
+    d3 s = o - v0;
+    double u = det_inv * dot(s, h);
+    if (!(u >= 0.0 && u <= 1.0)) return false;
+    d3 q = cross(s, edge1);
+    double v = det_inv * dot(d, q);
+    if (v < 0.0 || (u + v) > 1.0) return false;
+    double t = det_inv * dot(edge2, q);
+    if (t <= F64_EPS || t > t_max || t <= t_min) return false;
+    t_out = t; u_out = u; v_out = v;
+    return true;
+}
+// shape.rs:93-121
+RT_DEV bool sphere_hit(d3 center, double radius, d3 o, d3 d, double t_min, double t_max, double& t_out) {
+    d3 oc = o - center;
+    double a = length_squared(d);
+    double half_b = dot(oc, d);
+    double c = length_squared(oc) - radius * radius;
+    double discriminant = half_b * half_b - a * c;
+    if (discriminant < 0.0) return false;
+    double sqrt_discriminant = __builtin_sqrt(discriminant);
+    double root = (-half_b - sqrt_discriminant) / a;
+    if (root < t_min || root > t_max) {
+        root = (-half_b + sqrt_discriminant) / a;
+        if (root < t_min || root > t_max) return false;
+    }
+    t_out = root;
+    return true;
+}
+RT_DEV d3 moving_center(d3 c0, d3 c1, double time0, double time1, double time) {  // shape.rs:214-217
+    return c0 + (c1 - c0) * ((time - time0) / (time1 - time0));
+}
+// shape.rs:266-278
+RT_DEV bool rect_hit(double x0, double x1, double y0, double y1, double z, d3 o, d3 d, double t_min, double t_max, double& t_out) {
+    double t = (z - o.z) / d.z;
+    if (t < t_min || t > t_max) return false;
+    double x = o.x + d.x * t, y = o.y + d.y * t;
+    if (x < x0 || x > x1 || y < y0 || y > y1) return false;
+    t_out = t;
+    return true;
+}
+
+// ---- full hit record (hit.rs, mesh.rs:83-106, shape.rs:121-127, transform.rs:36-48) -------------
+struct HitRecord {
+    d3 point, normal;
+    double t, u, v;
+    uint32_t material;
+    bool front_face;
+};
+RT_DEV void spherical_uv(d3 p, double& u, double& v) {  // shape.rs:73-91
+    double theta = acos(-p.y);
+    double phi = atan2(-p.z, p.x) + PI;
+    u = phi / (2.0 * PI);
+    v = theta / PI;
+}
+RT_DEV void set_face_normal(HitRecord& hr, d3 ray_dir, d3 outward_normal) {  // hit.rs:40-47
+    hr.front_face = dot(ray_dir, outward_normal) < 0.0;
+    hr.normal = hr.front_face ? outward_normal : -outward_normal;
+}
+RT_DEV bool material_uses_uv(const SceneDev& sc, uint32_t material);
+
+// Rebuilds the reference HitRecord for the winning primitive.  `prim` / `inst` are indices into
+// the prims table (inst = enclosing INSTANCE primitive or RT_NONE).  The primitive test is re-run
+// on the same (possibly transformed) ray with t_max = t, which reproduces the same root / (u,v).
+RT_DEV bool full_hit(const SceneDev& sc, uint32_t prim, uint32_t inst, const Ray& ray, double t_min, double t_hit, HitRecord& hr) {
+    rt_prim p = sc.prims[prim];
+    uint32_t xf = p.xform;
+    if (inst != RT_NONE) xf = sc.prims[inst].xform;
+    Ray r = ray;
+    const double* m = nullptr;
+    if (xf != RT_NONE) {  // transform.rs:25-32
+        m = sc.xforms[xf].t_inv;
+        r.o = mat_mul_xyz(m, ray.o, 1.0);
+        r.d = mat_mul_xyz(m, ray.d, 0.0);
+    }
+    hr.material = p.material;
+    double t = 0.0;
+    if (p.kind == RT_PRIM_TRIANGLE) {
+        const rt_tri_verts& tv = sc.tri_verts[p.index];
+        double u, v;
+        if (!tri_hit(ld3(tv.v0), ld3(tv.v1), ld3(tv.v2), r.o, r.d, t_min, t_hit, t, u, v)) return false;
+        const rt_tri_attrs& ta = sc.tri_attrs[p.index];
+        double w = 1.0 - (u + v);
+        hr.normal = ((u * ld3(ta.n0)) + (v * ld3(ta.n1))) + (w * ld3(ta.n2));  // mesh.rs:95: u weights vertex 0 (reference quirk)
+        hr.u = ((u * ta.uv0[0]) + (v * ta.uv1[0])) + (w * ta.uv2[0]);
+        hr.v = ((u * ta.uv0[1]) + (v * ta.uv1[1])) + (w * ta.uv2[1]);
+        hr.point = ray_at(r, t);
+        hr.front_face = dot(r.d, hr.normal) > 0.0;  // mesh.rs:105
+    } else if (p.kind == RT_PRIM_SPHERE || p.kind == RT_PRIM_MOVING_SPHERE) {
+        d3 center; double radius;
+        if (p.kind == RT_PRIM_SPHERE) { const rt_sphere& s = sc.spheres[p.index]; center = ld3(s.center); radius = s.radius; }
+        else { const rt_moving_sphere& s = sc.moving[p.index]; center = moving_center(ld3(s.center0), ld3(s.center1), s.time0, s.time1, r.time); radius = s.radius; }
+        if (!sphere_hit(center, radius, r.o, r.d, t_min, t_hit, t)) return false;
+        hr.point = ray_at(r, t);
+        d3 normal = (hr.point - center) / radius;
+        hr.u = 0.0; hr.v = 0.0;
+        if (material_uses_uv(sc, p.material)) spherical_uv(normal, hr.u, hr.v);  // (u,v) only feed image textures
+        set_face_normal(hr, r.d, normal);
+    } else {  // RT_PRIM_AARECT, shape.rs:280-295
+        const rt_aarect& a = sc.rects[p.index];
+        if (!rect_hit(a.x0, a.x1, a.y0, a.y1, a.z, r.o, r.d, t_min, t_hit, t)) return false;
+        hr.point = ray_at(r, t);
+        hr.u = (hr.point.x - a.x0) / (a.x1 - a.x0);
+        hr.v = (hr.point.y - a.y0) / (a.y1 - a.y0);
+        set_face_normal(hr, r.d, mk(0.0, 0.0, 1.0));
+    }
+    hr.t = t;
+    if (m) {  // transform.rs:38-48
+        hr.point = ray_at(ray, t);
+        hr.normal = normalize(mat_t_mul_xyz0(m, hr.normal));
+    }
+    return true;
+}
+
+// ---- texture.rs / image.rs:81-94 ------------------------------------------------------------------
+RT_DEV uint32_t sat_u32(double d) {  // Rust `as u32`
+    if (!(d > 0.0)) return 0u;
+    if (d >= 4294967295.0) return 4294967295u;
+    return (uint32_t)d;
+}
+RT_DEV d3 tex_sample(const SceneDev& sc, uint32_t tex, double u, double v, d3 p) {
+    rt_texture t = sc.textures[tex];
+    for (int depth = 0; depth < 8 && t.kind == RT_TEX_CHECKER; ++depth) {  // texture.rs:35-45
+        double sines = sin(10.0 * p.x) * sin(10.0 * p.y) * sin(10.0 * p.z);
+        t = sc.textures[sines < 0.0 ? t.a : t.b];
+    }
+    if (t.kind == RT_TEX_IMAGE) {
+        double uu = u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
+        double vc = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+        double vv = 1.0 - vc;
+        uint32_t x = sat_u32((double)t.b * uu), y = sat_u32((double)t.c * vv);
+        x = x < t.b - 1 ? x : t.b - 1; y = y < t.c - 1 ? y : t.c - 1;
+        const uint8_t* px = sc.texels + t.a + ((size_t)y * t.b + x) * 3;
+        double r = (double)px[0] / 255.0, g = (double)px[1] / 255.0, b = (double)px[2] / 255.0;  // main.rs:900-903
+        return mk(r * r, g * g, b * b);
+    }
+    return ld3(t.colour);
+}
+// mat_uses_uv[m] != 0 iff material m's texture tree contains an image texture (computed at upload)
+RT_DEV bool material_uses_uv(const SceneDev& sc, uint32_t material) { return sc.mat_uses_uv[material] != 0; }
+
+RT_DEV d3 material_emitted(const SceneDev& sc, uint32_t material, double u, double v, d3 p) {  // material.rs:10-12,125-127
+    const rt_material& m = sc.materials[material];
+    return m.kind == RT_MAT_DIFFUSE_LIGHT ? tex_sample(sc, m.texture, u, v, p) : mk(0.0, 0.0, 0.0);
+}
+
+// ---- pdf.rs as a tagged value -----------------------------------------------------------------------
+enum PdfKind { PDF_COSINE, PDF_UNIFORM_HEMI, PDF_UNIFORM_SPHERE, PDF_FUZZY, PDF_DIELECTRIC, PDF_CONE };
+struct Pdf {
+    int kind;
+    d3 a;      // COSINE/HEMI/CONE: basis w | SPHERE: center | FUZZY: dir | DIELECTRIC: reflect_dir
+    d3 b;      // DIELECTRIC: refract_dir
+    double s;  // CONE: cos_theta_max | SPHERE: radius | FUZZY: fuzz | DIELECTRIC: reflectance
+    bool cannot_refract;
+};
+RT_DEV double reflectance(double cosine, double ref_idx) {  // material.rs:87-92, powi(5) = x*((x*x)*(x*x))
+    double r0 = (1.0 - ref_idx) / (1.0 + ref_idx);
+    r0 = r0 * r0;
+    double x = 1.0 - cosine;
+    double x2 = x * x;
+    return r0 + ((1.0 - r0) * (x * (x2 * x2)));
+}
+RT_DEV bool pdf_is_delta(const Pdf& p) { return p.kind == PDF_FUZZY || p.kind == PDF_DIELECTRIC; }
+RT_DEV double pdf_value(const Pdf& p, d3 direction) {
+    switch (p.kind) {
+        case PDF_COSINE: { double cosine = dot(normalize(direction), p.a); return cosine <= 0.0 ? 0.0 : cosine / PI; }  // pdf.rs:30-38
+        case PDF_UNIFORM_HEMI: return 0.5 * FRAC_1_PI;                       // pdf.rs:58-60
+        case PDF_UNIFORM_SPHERE: return 1.0 / (4.0 * PI * (p.s * p.s));      // pdf.rs:73-75
+        case PDF_CONE: return 1.0 / (2.0 * PI * (1.0 - p.s));                // pdf.rs:241-250
+        default: return 0.0;
+    }
+}
+RT_DEV d3 pdf_generate(const Pdf& p, Rng& rng) {
+    switch (p.kind) {
+        case PDF_COSINE: { Onb b = onb_from_w(p.a); return normalize(onb_local(b, rand_cosine_hemisphere(rng))); }  // pdf.rs:40-42
+        case PDF_UNIFORM_HEMI: { Onb b = onb_from_w(p.a); return normalize(onb_local(b, rand_hemisphere(rng))); }   // pdf.rs:62-64
+        case PDF_UNIFORM_SPHERE: return (normalize(rand_in_unit_sphere(rng)) * p.s) + p.a;                          // pdf.rs:77-79
+        case PDF_FUZZY: { d3 s = rand_in_unit_sphere(rng); return normalize(p.a + (s * p.s)); }                      // pdf.rs:126-128
+        case PDF_DIELECTRIC: {                                                                                       // pdf.rs:167-173
+            if (p.cannot_refract) return p.a;
+            return p.s > rng.next_f64() ? p.a : p.b;
+        }
+        default: {                                                                                                   // pdf.rs:252-262
+            Onb b = onb_from_w(p.a);
+            double r1 = rng.next_f64();
+            double cos_theta = (1.0 - r1) + (r1 * p.s);
+            double sin_theta = __builtin_sqrt(1.0 - (cos_theta * cos_theta));
+            double phi = rng.next_f64() * 2.0 * PI;
+            double sn, cs;
+            sincos(phi, &sn, &cs);
+            return onb_local(b, mk(cs * sin_theta, sn * sin_theta, cos_theta));
+        }
+    }
+}
+// material.rs scattering_pdf: false for DiffuseLight
+RT_DEV bool scattering_pdf(const rt_material& m, const Ray& ray_in, const HitRecord& hr, Pdf& out) {
+    out.cannot_refract = false; out.b = mk(0, 0, 0); out.s = 0.0;
+    if (m.kind == RT_MAT_LAMBERTIAN) { out.kind = PDF_COSINE; out.a = hr.normal; return true; }              // material.rs:32-36
+    if (m.kind == RT_MAT_METAL) {                                                                              // material.rs:71-74, pdf.rs:87-91
+        out.kind = PDF_FUZZY; out.a = normalize(reflect(normalize(ray_in.d), hr.normal)); out.s = m.fuzz; return true;
+    }
+    if (m.kind == RT_MAT_DIELECTRIC) {                                                                         // material.rs:95-106, pdf.rs:142-160
+        double ior = hr.front_face ? 1.0 / m.ior : m.ior;
+        d3 unit_direction = normalize(ray_in.d);
+        double cos_theta = fmin(dot(-unit_direction, hr.normal), 1.0);
+        double sin_theta = __builtin_sqrt(1.0 - cos_theta * cos_theta);
+        out.kind = PDF_DIELECTRIC;
+        out.cannot_refract = (ior * sin_theta) > 1.0;
+        out.a = normalize(reflect(unit_direction, hr.normal));
+        out.b = normalize(refract(unit_direction, hr.normal, ior));
+        out.s = reflectance(cos_theta, ior);
+        return true;
+    }
+    return false;
+}
+RT_DEV d3 material_brdf(const SceneDev& sc, const rt_material& m, const HitRecord& hr, d3 out_dir) {
+    if (m.kind == RT_MAT_LAMBERTIAN) return tex_sample(sc, m.texture, hr.u, hr.v, hr.point) / PI;  // material.rs:38-42
+    if (m.kind == RT_MAT_METAL) return ld3(m.albedo) / dot(out_dir, hr.normal);                   // material.rs:65-69
+    if (m.kind == RT_MAT_DIELECTRIC) return mk(1.0, 1.0, 1.0) / dot(out_dir, hr.normal);          // material.rs:108-112
+    return mk(0.0, 0.0, 0.0);
+}
+// Sphere::pdf_for_point, shape.rs:36-53
+RT_DEV Pdf light_pdf_for_point(const rt_light& l, d3 point) {
+    Pdf p; p.cannot_refract = false; p.b = mk(0, 0, 0);
+    d3 c = ld3(l.center);
+    if (length_squared(point - c) <= l.radius * l.radius) { p.kind = PDF_UNIFORM_SPHERE; p.a = c; p.s = l.radius; return p; }
+    double sin_theta_max_2 = (l.radius * l.radius) / length_squared(point - c);
+    p.kind = PDF_CONE; p.a = normalize(c - point); p.s = __builtin_sqrt(fmax(0.0, 1.0 - sin_theta_max_2));
+    return p;
+}
+RT_DEV double power_heuristic(double pdf_f, double pdf_g) {  // integrator.rs:10-15 with num_f = num_g = 1
+    double f = 1.0 * pdf_f, g = 1.0 * pdf_g;
+    return (f * f) / ((f * f) + (g * g));
+}
+RT_DEV d3 background_colour(uint32_t bg, const Ray& ray) {  // main.rs:37-48
+    if (bg == RT_BG_SKY) {
+        d3 unit_dir = normalize(ray.d);
+        double t = 0.5 * unit_dir.y + 1.0;
+        return mk(1.0, 1.0, 1.0) * (1.0 - t) + mk(0.5, 0.7, 1.0) * t;
+    }
+    return mk(0.0, 0.0, 0.0);
+}
+
+}  // namespace rt

@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_available():
+    try:
+        import raytracing_amd._ffi as ffi
+        return ffi.hip().rt_device_count() > 0
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    import raytracing_amd as rt
+    # No silent skip on the GPU box: a missing library or device is a failure of the gpu-marked test.
+    ctx = rt.Context(0)
+    yield ctx
+    ctx.close()

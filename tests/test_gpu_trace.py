@@ -1,0 +1,169 @@
+"""GPU parity, row (a3..a13): closest-hit (primitive id, instance id, t) from the HIP traversal kernel
+must be BIT-EXACT against the oracle's Scene::hit on identical rays, through the C ABI."""
+import numpy as np
+import pytest
+
+import oracle_ffi as orc
+import raytracing_amd as rt
+from scene_text import SceneText, scale, translate
+
+pytestmark = pytest.mark.gpu
+
+SCENES = [  # (name, legacy_bvh, width, height) -- sizes keep the oracle (1 ms/ray on the pagoda) to seconds
+    ("simple_triangle", False, 96, 54),
+    ("simple_triangle", True, 96, 54),
+    ("simple", False, 96, 54),
+    ("cornell", False, 96, 54),
+    ("cornell", True, 96, 54),
+    ("sphere", False, 64, 36),
+    ("random", False, 128, 72),
+    ("random_blur", False, 64, 36),
+    ("simple_light", False, 64, 36),
+    ("mesh", False, 64, 36),
+]
+
+
+def _pair(name, legacy_bvh, seed=5):
+    hs = rt.HostScene.builtin(name, bvh_seed=seed, legacy_bvh=legacy_bvh)
+    return hs, orc.OracleScene(hs.describe())
+
+
+def _assert_same_hits(g, o):
+    gp, gi, gt = g[:3]
+    op, oi, ot = o[:3]
+    assert np.array_equal(gp, op), f"{(gp != op).sum()} primitive ids differ"
+    assert np.array_equal(gi, oi), f"{(gi != oi).sum()} instance ids differ"
+    assert np.array_equal(gt.view(np.uint64), ot.view(np.uint64)), f"{(gt.view(np.uint64) != ot.view(np.uint64)).sum()} t values differ in bits"
+
+
+@pytest.mark.parametrize("name,legacy_bvh,w,h", SCENES)
+def test_primary_hits_bit_exact(gpu_ctx, name, legacy_bvh, w, h):
+    hs, osc = _pair(name, legacy_bvh)
+    gs = gpu_ctx.upload(hs)
+    rays = osc.primary_rays(w, h, 0, 0x5EED)
+    g = gs.trace_closest(rays, 0.001, 100000.0, counters=True)
+    o = osc.trace_closest(rays, 0.001, 100000.0)
+    _assert_same_hits(g, o)
+    assert (o[0] != rt.NONE).sum() > 0
+    # same traversal order => same number of box / triangle / sphere tests as the reference recursion
+    assert list(map(int, g[3])) == list(map(int, o[3][:3])), (g[3], o[3])
+    gs.close()
+
+
+@pytest.mark.parametrize("name,legacy_bvh", [("random", False), ("cornell", False), ("mesh", False), ("simple", False)])
+def test_incoherent_rays_bit_exact(gpu_ctx, name, legacy_bvh):
+    # bounce-like rays: random origins near the scene, random (un-normalised) directions, shadow-ray window
+    hs, osc = _pair(name, legacy_bvh, seed=11)
+    gs = gpu_ctx.upload(hs)
+    rng = np.random.default_rng(7)
+    n = 1500 if name == "mesh" else 6000
+    rays = np.zeros((n, 7))
+    rays[:, :3] = rng.uniform(-6, 6, (n, 3)) + (np.array([5, 12, 5]) if name == "mesh" else 0)
+    rays[:, 3:6] = rng.normal(size=(n, 3)) * rng.uniform(0.1, 3.0, (n, 1))
+    rays[:, 6] = rng.uniform(0, 1, n)
+    rays[::97, 4] = 0.0   # exact zero direction components: +-inf / NaN slab paths (bounding_box.rs:29)
+    rays[::89, 3] = 0.0
+    _assert_same_hits(gs.trace_closest(rays, 0.001, 10000.0), osc.trace_closest(rays, 0.001, 10000.0))
+    gs.close()
+
+
+def test_gpu_primary_rays_match_oracle(gpu_ctx):
+    # camera.rs:83-101 + main.rs:996-999 with the shared Philox stream: rays agree to the last bit
+    for name in ("random_blur", "mesh", "simple"):
+        hs, osc = _pair(name, False)
+        gs = gpu_ctx.upload(hs)
+        for s in (0, 3):
+            g = gs.primary_rays(40, 23, s, 99); o = osc.primary_rays(40, 23, s, 99)
+            assert np.array_equal(g.view(np.uint64), o.view(np.uint64))
+        gs.close()
+
+
+def test_reference_kats_through_abi(gpu_ctx):
+    # KAT-1 (bvh.rs:129-173): t == 1.0 exactly
+    s = SceneText(); m = s.lambertian_rgb(.5, .5, .5)
+    me = s.mesh([(-1, -1, 0), (1, 1, 0), (-1, 1, 0)], [(0, 0, 1)] * 3, [(0, 0), (1, 1), (0, 1)], [(0, 1, 2)], m)
+    tri = s.triangle(me, 0)
+    gs = gpu_ctx.upload(rt.HostScene.from_description(s.finish([tri], build_bvh=True)))
+    p, i, t = gs.trace_closest([[-0.5, 0, 1, 0, 0, -1, 0]], 0.00001, 10000.0)
+    assert p[0] == tri and t[0] == 1.0
+    gs.close()
+    # KAT-11 (transform.rs:81-101): unit sphere misses, scaled x2 hits at the grazing point t == 1
+    s = SceneText(); m = s.lambertian_rgb(.5, .5, .5)
+    sp = s.sphere((0, 0, 0), 1.0, m)
+    gs = gpu_ctx.upload(rt.HostScene.from_description(s.finish([sp])))
+    p, i, t = gs.trace_closest([[0, 2, 1, 0, 0, -1, 0]], 0.0, 100.0)
+    assert p[0] == rt.NONE
+    gs.close()
+    s = SceneText(); m = s.lambertian_rgb(.5, .5, .5)
+    sp = s.sphere((0, 0, 0), 1.0, m); tr = s.transformed(s.xform(scale(2, 2, 2)), sp)
+    gs = gpu_ctx.upload(rt.HostScene.from_description(s.finish([tr])))
+    p, i, t = gs.trace_closest([[0, 2, 1, 0, 0, -1, 0]], 0.0, 100.0)
+    assert p[0] == sp and i[0] == tr and t[0] == 1.0
+    gs.close()
+    # KAT-7 (mesh.rs:203-239): edge hit (v == 0) is accepted
+    s = SceneText(); m = s.lambertian_rgb(0, 0, 0)
+    me = s.mesh([(1, 0, -1), (0, 1, -1), (0, 0, -1)], [(0, 0, 1)] * 3, [(1, 0), (0, 1), (0, 0)], [(0, 1, 2)], m)
+    tri = s.triangle(me, 0)
+    text = s.finish([tri])
+    gs = gpu_ctx.upload(rt.HostScene.from_description(text))
+    d = np.array([0.5, 0.5, -1.0]); d = d * (1.0 / np.sqrt(d @ d))
+    ray = [[0, 0, 0, *d, 0]]
+    g = gs.trace_closest(ray, 0.01, 10.0); o = orc.OracleScene(text).trace_closest(ray, 0.01, 10.0)
+    assert g[0][0] == tri
+    _assert_same_hits(g, o)
+    gs.close()
+
+
+def test_ties_go_to_the_later_primitive(gpu_ctx):
+    # two coincident triangles: the reference accepts t == t_max (mesh.rs:79), so the LATER one in
+    # traversal order wins (hittable.rs:45-47 / bvh.rs:103-105); same through a BVH
+    for build_bvh in (False, True):
+        s = SceneText(); m = s.lambertian_rgb(.5, .5, .5)
+        me = s.mesh([(-1, -1, 0), (1, 1, 0), (-1, 1, 0)], [(0, 0, 1)] * 3, [(0, 0)] * 3, [(0, 1, 2), (0, 1, 2), (0, 1, 2)], m)
+        ids = [s.triangle(me, k) for k in range(3)]
+        text = s.finish(ids, build_bvh=build_bvh)
+        gs = gpu_ctx.upload(rt.HostScene.from_description(text))
+        ray = [[-0.5, 0.2, 1, 0, 0, -1, 0]]
+        g = gs.trace_closest(ray, 0.001, 100.0); o = orc.OracleScene(text).trace_closest(ray, 0.001, 100.0)
+        _assert_same_hits(g, o)
+        assert g[0][0] == o[0][0] and g[0][0] != ids[0]
+        gs.close()
+
+
+def test_empty_and_ragged_batches(gpu_ctx):
+    hs, osc = _pair("random", False)
+    gs = gpu_ctx.upload(hs)
+    p, i, t = gs.trace_closest(np.zeros((0, 7)), 0.001, 1e5)
+    assert p.size == 0
+    rays = osc.primary_rays(37, 13, 1, 4)     # 481 rays: not a multiple of the wave (64) or block (256)
+    for n in (1, 63, 64, 65, 481):
+        _assert_same_hits(gs.trace_closest(rays[:n], 0.001, 1e5), osc.trace_closest(rays[:n], 0.001, 1e5))
+    gs.close()
+
+
+def test_device_f64_div_sqrt_are_ieee(gpu_ctx):
+    # SURVEY.md section 7 "hard parts": device `/` and sqrt must round like the host's, checked on 2e6 inputs
+    rng = np.random.default_rng(1)
+    n = 2_000_000
+    a = np.abs(rng.standard_normal(n)) * 10.0 ** rng.uniform(-30, 30, n)
+    b = rng.standard_normal(n) * 10.0 ** rng.uniform(-30, 30, n)
+    q, s = gpu_ctx.ieee_div_sqrt(a, b)
+    oq, os_ = orc.div_sqrt(a, b)
+    assert np.array_equal(q.view(np.uint64), oq.view(np.uint64))
+    assert np.array_equal(s.view(np.uint64), os_.view(np.uint64))
+
+
+def test_bad_blobs_are_rejected(gpu_ctx):
+    hs = rt.HostScene.builtin("simple_triangle")
+    blob = bytearray(hs.blob())
+    with pytest.raises(rt.RtError):
+        gpu_ctx.upload(bytes(blob[:100]))
+    bad = bytearray(blob); bad[0] ^= 0xFF
+    with pytest.raises(rt.RtError):
+        gpu_ctx.upload(bytes(bad))
+    h = hs.header()
+    bad = bytearray(blob)
+    off = h.off_nodes + 48   # node[0].skip -> backwards link would loop forever: must be refused on the host
+    bad[off:off + 4] = (0).to_bytes(4, "little")
+    with pytest.raises(rt.RtError):
+        gpu_ctx.upload(bytes(bad))

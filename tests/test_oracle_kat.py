@@ -1,0 +1,136 @@
+"""The oracle pinned against every known-answer test the reference holds for this path
+(SURVEY.md section 4 / 8c, KAT-1..11).  Inputs and expected values are the reference tests' own
+constants; the cited lines are where each lives under /root/reference."""
+import math
+
+import numpy as np
+
+import oracle_ffi as orc
+from scene_text import SceneText, scale
+
+
+def _tri_scene(verts, normals, uvs, faces, build_bvh):
+    s = SceneText()
+    m = s.lambertian_rgb(0.5, 0.5, 0.5)
+    me = s.mesh(verts, normals, uvs, faces, m)
+    ids = [s.triangle(me, i) for i in range(len(faces))]
+    return s.finish(ids, build_bvh=build_bvh), ids
+
+
+def test_kat1_bvh_intersect():  # renderer/src/bvh.rs:129-173: t == 1.0 exactly through BVH + triangle
+    text, ids = _tri_scene([(-1, -1, 0), (1, 1, 0), (-1, 1, 0)], [(0, 0, 1)] * 3, [(0, 0), (1, 1), (0, 1)], [(0, 1, 2)], True)
+    sc = orc.OracleScene(text)
+    prim, inst, t, _ = sc.trace_closest([[-0.5, 0, 1, 0, 0, -1, 0]], 0.00001, 10000.0)
+    assert prim[0] == ids[0] and t[0] == 1.0
+
+
+def test_kat2_aabb_intersect_90():  # renderer/src/bounding_box.rs:53-67 (dir.y == 0 -> +-inf path)
+    assert orc.aabb_hit([-1, -1, -2, 1, 1, -1], [-2, 0, 0, 2, 0, -1, 1.0], 0.0001, 10000.0)
+
+
+def test_aabb_axes_are_independent():
+    # bounding_box.rs:37-38 shadow t_min/t_max inside the loop: each axis is tested against the
+    # ORIGINAL interval.  A ray that crosses the x slab and the y slab at disjoint t ranges misses
+    # the box geometrically but the reference (and so the oracle) reports a hit.
+    box = [0, 10, 0, 1, 11, 1]            # x in [0,1], y in [10,11]
+    ray = [-1, -1, 0.5, 1, 1, 0, 0]       # x slab at t in [1,2], y slab at t in [11,12]
+    assert orc.aabb_hit(box, ray, 0.001, 1e5)
+    assert not orc.aabb_hit(box, ray, 0.001, 10.0)   # y slab now outside [t_min, t_max]
+
+
+def _spheres(specs):
+    s = SceneText()
+    m = s.lambertian_rgb(0, 0, 0)
+    ids = [s.sphere(c, r, m) for c, r in specs]
+    return orc.OracleScene(s.finish(ids)), ids
+
+
+def test_kat3_single_bounding_box():  # renderer/src/hittable.rs:128-150
+    sc, ids = _spheres([((0, 0, 0), 0.5)])
+    assert np.array_equal(sc.list_bbox(ids), [-0.5, -0.5, -0.5, 0.5, 0.5, 0.5])
+
+
+def test_kat4_overlap_bounding_box():  # renderer/src/hittable.rs:152-181
+    sc, ids = _spheres([((0, 0, 0), 0.5), ((0, 0, 0), 0.2)])
+    assert np.array_equal(sc.list_bbox(ids), [-0.5, -0.5, -0.5, 0.5, 0.5, 0.5])
+
+
+def test_kat5_two_bounding_box():  # renderer/src/hittable.rs:183-212
+    sc, ids = _spheres([((-0.5, -0.5, -0.5), 0.5), ((0.5, 0.5, 0.5), 0.5)])
+    assert np.array_equal(sc.list_bbox(ids), [-1, -1, -1, 1, 1, 1])
+
+
+def test_kat6_mesh_bbox():  # renderer/src/mesh.rs:175-201
+    text, ids = _tri_scene([(-1, -1, -1), (-1, 1, -1), (1, 1.1, -1)], [(0, 0, 0)] * 3, [(0, 0)] * 3, [(0, 1, 2)], False)
+    assert np.array_equal(orc.OracleScene(text).object_bbox(ids[0]), [-1, -1, -1, 1, 1.1, -1])
+
+
+def test_kat7_mesh_hit():  # renderer/src/mesh.rs:203-239: must hit (unwrap); the hit is on an edge (v == 0)
+    text, ids = _tri_scene([(1, 0, -1), (0, 1, -1), (0, 0, -1)], [(0, 0, 1)] * 3, [(1, 0), (0, 1), (0, 0)], [(0, 1, 2)], False)
+    d = np.array([0.5, 0.5, -1.0])
+    d = d * (1.0 / math.sqrt(float(d @ d)))   # glam normalize = v * (1/len)
+    hr = orc.OracleScene(text).object_hit(ids[0], [0, 0, 0, *d, 0], 0.01, 10.0)
+    assert hr is not None
+    assert abs(hr[6] - math.sqrt(1.5)) < 1e-15 and abs(hr[0] - 0.5) < 1e-15 and abs(hr[1] - 0.5) < 1e-15 and hr[2] == -1.0
+
+
+def test_kat8_9_10_tiles():  # renderer/src/image.rs:100-162
+    import ctypes as C
+    L = orc.lib()
+    out = (C.c_uint32 * 4)(); xy = (C.c_uint32 * 2)()
+    L.orc_get_tile(100, 100, 0, 0, 100, 100, out); assert list(out) == [0, 0, 100, 100]
+    L.orc_tile_xy(0, 0, 100, 100, 0, xy); assert list(xy) == [0, 0]
+    L.orc_tile_xy(0, 0, 100, 100, 100 * 100 - 1, xy); assert list(xy) == [99, 99]
+    L.orc_get_tile(100, 100, 50, 50, 50, 50, out); assert list(out) == [50, 50, 50, 50]
+    L.orc_tile_xy(50, 50, 50, 50, 0, xy); assert list(xy) == [50, 50]
+    L.orc_tile_xy(50, 50, 50, 50, 49, xy); assert list(xy) == [99, 50]
+    L.orc_get_tile(100, 100, 90, 0, 50, 50, out); assert list(out) == [90, 0, 10, 50]   # get_tile_on_boundary
+    L.orc_tile_xy(90, 0, 10, 50, 10, xy); assert list(xy) == [90, 1]
+
+
+def test_kat11_transformed_sphere():  # renderer/src/transform.rs:81-101 (grazing: discriminant == 0 -> t == 1)
+    s = SceneText()
+    m = s.lambertian_rgb(0.5, 0.5, 0.5)
+    sp = s.sphere((0, 0, 0), 1.0, m)
+    tr = s.transformed(s.xform(scale(2, 2, 2)), sp)
+    sc = orc.OracleScene(s.finish([tr]))
+    ray = [0, 2, 1, 0, 0, -1, 0]
+    assert sc.object_hit(sp, ray, 0.0, 100.0) is None
+    hr = sc.object_hit(tr, ray, 0.0, 100.0)
+    assert hr is not None and hr[6] == 1.0 and hr[10] == sp and hr[11] == tr
+
+
+def test_philox_known_answers():  # Random123 kat_vectors, philox4x32-10
+    assert [hex(x) for x in orc.philox([0, 0, 0, 0], 0, 0)] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    assert [hex(x) for x in orc.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], 0xa4093822, 0x299f31d0)] == ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+    assert [hex(x) for x in orc.philox([0xffffffff] * 4, 0xffffffff, 0xffffffff)] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+
+
+def test_bvh_equals_linear_list():
+    # oracle-internal cross-check: BVH hit == linear-list hit (hittable.rs:41-53) on the
+    # same objects, for several injected axis sequences -- same (prim, t) for every ray
+    import raytracing_amd as rt
+    base = rt.HostScene.builtin("random", bvh_seed=1).describe().decode()
+    lin = orc.OracleScene(base.replace("build_bvh 1", "build_bvh 0"))
+    rays = lin.primary_rays(48, 27, 0, 3)
+    p0, _, t0, _ = lin.trace_closest(rays, 0.001, 1e5)
+    for seed in (1, 2, 99):
+        b = orc.OracleScene(base.replace("bvh_seed 1", f"bvh_seed {seed}"))
+        p1, _, t1, _ = b.trace_closest(rays, 0.001, 1e5)
+        assert np.array_equal(t0, t1)
+        # ties between different primitives are order dependent; none occur for these rays
+        assert np.array_equal(p0, p1)
+
+
+def test_furnace_lambertian():
+    # analytic radiometry check: a Lambertian surface with albedo a under a uniform
+    # sky of radiance 1 (depth 1 bounce chain truncated at depth 2) returns exactly a per sample for the
+    # BRDF integrator: brdf*cos/pdf = (a/pi)*cos/(cos/pi) = a.
+    s = SceneText()
+    lit = s.diffuse_light(s.solid(1, 1, 1))
+    env = s.sphere((0, 0, 0), -50.0, lit)          # inward-facing emissive shell
+    ball = s.sphere((0, 0, 0), 1.0, s.lambertian_rgb(0.25, 0.5, 0.75))
+    sc = orc.OracleScene(s.finish([env, ball]))
+    img, st = sc.render(16, 9, 0, 8, 4, 2)
+    centre = img[4, 8] / 8
+    assert np.allclose(centre, [0.25, 0.5, 0.75], rtol=1e-12)
