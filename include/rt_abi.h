@@ -66,6 +66,8 @@ typedef struct rt_node {
     uint32_t prim1;  /* leaf node: second primitive (bvh.rs right), RT_NONE if absent or == prim0 */
 } rt_node;
 #define RT_NODE_NO_BOX 1u
+#define RT_NODE_DUP_RIGHT 2u /* 1-object leaf (bvh.rs:37-43): the reference tests prim0 a second time as `right`;
+                                the kernel skips the re-test (same record) but counts it in the test counters */
 
 #define RT_PRIM_TRIANGLE 0u
 #define RT_PRIM_SPHERE 1u

@@ -139,6 +139,11 @@ RT_DEV void traverse(const SceneDev& sc, uint32_t first, uint32_t end, d3 o, d3 
         if (p0 != RT_NONE && __ballot(pass) != 0ull) {
             test_prim<LEVEL, COUNT>(sc, p0, pass, o, d, time, t_min, h, inst_prim, cached_xf, xo, xd, cnt);
             if (p1 != RT_NONE) test_prim<LEVEL, COUNT>(sc, p1, pass, o, d, time, t_min, h, inst_prim, cached_xf, xo, xd, cnt);
+            if (COUNT && (flags & RT_NODE_DUP_RIGHT)) {  // reference-order count of the skipped duplicate test
+                const uint32_t k = as_const(sc.prims)[p0].kind;
+                if (k == RT_PRIM_TRIANGLE) cnt.tri += pass ? 1u : 0u;
+                else if (k == RT_PRIM_SPHERE || k == RT_PRIM_MOVING_SPHERE) cnt.sph += pass ? 1u : 0u;
+            }
         }
         if (__ballot(next == i + 1u) != 0ull) i = i + 1u;
         else i = wave_min_u32(next);

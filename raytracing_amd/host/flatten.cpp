@@ -236,6 +236,7 @@ struct Flattener {
             uint32_t p0 = make_prim(n->left.get(), RT_NONE, RT_NONE, under_instance_xform);
             uint32_t p1 = n->right.get() == n->left.get() ? RT_NONE : make_prim(n->right.get(), RT_NONE, RT_NONE, under_instance_xform);
             nodes[idx].prim0 = p0; nodes[idx].prim1 = p1;
+            if (n->right.get() == n->left.get()) nodes[idx].flags |= RT_NODE_DUP_RIGHT;
         }
         nodes[idx].skip = (uint32_t)nodes.size();
     }
