@@ -167,3 +167,25 @@ def test_bad_blobs_are_rejected(gpu_ctx):
     bad[off:off + 4] = (0).to_bytes(4, "little")
     with pytest.raises(rt.RtError):
         gpu_ctx.upload(bytes(bad))
+
+
+def test_gpu_matches_committed_golden_vectors(gpu_ctx):
+    # tests/golden/oracle_vectors.npz (made by tests/golden/make_golden.py): hits bit-exact, radiance to 1e-9
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_vectors.npz"))
+    for name in ("simple_triangle", "random", "cornell", "simple", "sphere", "mesh"):
+        hs = rt.HostScene.builtin(name, bvh_seed=5)
+        gs = gpu_ctx.upload(hs)
+        w, h = map(int, g[f"{name}_wh"])
+        rays = g[f"{name}_rays"]
+        prim, inst, t, cnt = gs.trace_closest(rays, 0.001, 100000.0, counters=True)
+        assert np.array_equal(prim, g[f"{name}_prim"]) and np.array_equal(inst, g[f"{name}_inst"])
+        assert np.array_equal(t.view(np.uint64), g[f"{name}_t"].view(np.uint64))
+        assert list(map(int, cnt)) == list(map(int, g[f"{name}_cnt"][:3]))
+        picks = g[f"{name}_picks"]
+        for integ in range(4):
+            got = gs.sample_radiance(w, h, picks[:, 1] * w + picks[:, 0], picks[:, 2], 5, integ, 77)
+            ref = g[f"{name}_rad{integ}"]
+            ok = (np.abs(got - ref) <= 1e-9 * (np.abs(ref) + 1e-3)) | (np.isnan(got) & np.isnan(ref))
+            assert ok.all(axis=1).mean() >= 0.97, (name, integ)
+        gs.close()
