@@ -53,7 +53,7 @@ extern "C" {
  * All offsets are bytes from the start of the blob and 16-byte aligned.
  * ------------------------------------------------------------------------------------------- */
 #define RT_BLOB_MAGIC 0x42535452u
-#define RT_BLOB_VERSION 1u
+#define RT_BLOB_VERSION 2u
 
 /* Threaded BVH node, 64 B, pre-order (DFS, left first): the reference's fixed left-then-right
  * recursion (bvh.rs:91-106) needs no per-lane stack once every node stores where to go when its
@@ -77,7 +77,7 @@ typedef struct rt_node {
 
 typedef struct rt_prim {
     uint32_t kind;
-    uint32_t index;     /* into the kind's table; INSTANCE: first node of the sub-BVH */
+    uint32_t index;     /* TRIANGLE: rt_tri_attrs index; INSTANCE: first node of the sub-BVH; else 0 */
     uint32_t xform;     /* rt_xform index of the enclosing Transformed, or RT_NONE */
     uint32_t material;  /* rt_material index (RT_NONE for INSTANCE) */
     uint32_t object_id; /* id of the primitive object in the scene description */
@@ -86,11 +86,16 @@ typedef struct rt_prim {
     uint32_t pad;
 } rt_prim;
 
-typedef struct rt_tri_verts { double v0[3], v1[3], v2[3]; } rt_tri_verts;                 /* 72 B  */
-typedef struct rt_tri_attrs { double n0[3], n1[3], n2[3]; double uv0[2], uv1[2], uv2[2]; } rt_tri_attrs; /* 120 B */
-typedef struct rt_sphere { double center[3]; double radius; } rt_sphere;                  /* 32 B  */
-typedef struct rt_moving_sphere { double center0[3], center1[3]; double time0, time1, radius; } rt_moving_sphere; /* 72 B */
-typedef struct rt_aarect { double x0, x1, y0, y1, z; } rt_aarect;                         /* 40 B  */
+/* Intersection record, 80 B, PARALLEL to the prims table (geom[p] belongs to prims[p]): everything the
+ * primitive test reads, fetched with one wave-uniform scalar load.  d[] by kind:
+ *   TRIANGLE       v0(3), e1 = v1 - v0 (3), e2 = v2 - v0 (3): the edges are the first two statements of
+ *                  mesh.rs:55-56, evaluated once on the host in f64 (same IEEE subtraction, same bits)
+ *   SPHERE         center(3), radius
+ *   MOVING_SPHERE  center_0(3), center_1(3), time_0, time_1, radius
+ *   AARECT         x0, x1, y0, y1, z
+ *   INSTANCE       first node, one-past-last node of the sub-BVH (exact small integers) */
+typedef struct rt_geom { double d[9]; uint32_t kind; uint32_t xform; } rt_geom;
+typedef struct rt_tri_attrs { double n0[3], n1[3], n2[3]; double uv0[2], uv1[2], uv2[2]; } rt_tri_attrs; /* 120 B, shading only */
 typedef struct rt_xform { double t_inv[16]; } rt_xform; /* column-major inverse of the Transformed matrix (transform.rs:14-20) */
 
 #define RT_MAT_LAMBERTIAN 0u
@@ -133,12 +138,12 @@ typedef struct rt_camera { /* renderer/src/camera.rs:9-19 */
 typedef struct rt_blob_header {
     uint32_t magic, version;
     uint64_t total_bytes;
-    uint32_t n_nodes, n_prims, n_tris, n_spheres, n_moving_spheres, n_rects, n_xforms, n_materials, n_textures, n_lights;
+    uint32_t n_nodes, n_prims, n_tris, n_spheres, n_moving_spheres, n_rects, n_xforms, n_materials, n_textures, n_lights; /* n_tris..n_rects: counts by kind (n_tris = rt_tri_attrs entries) */
     uint32_t n_texel_bytes;
     uint32_t root_node; /* first node of the scene-level traversal (BVH root or first list item) */
     uint32_t root_end;  /* one past the last node of the scene-level traversal */
     uint32_t background;
-    uint64_t off_nodes, off_prims, off_tri_verts, off_tri_attrs, off_spheres, off_moving_spheres, off_rects, off_xforms,
+    uint64_t off_nodes, off_prims, off_geom, off_tri_attrs, reserved0, reserved1, reserved2, off_xforms,
         off_materials, off_textures, off_texels, off_lights;
     rt_camera camera;
     uint64_t bvh_seed;

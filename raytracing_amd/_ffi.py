@@ -48,8 +48,8 @@ class BlobHeader(C.Structure):
                 ("n_nodes", u32), ("n_prims", u32), ("n_tris", u32), ("n_spheres", u32), ("n_moving_spheres", u32),
                 ("n_rects", u32), ("n_xforms", u32), ("n_materials", u32), ("n_textures", u32), ("n_lights", u32),
                 ("n_texel_bytes", u32), ("root_node", u32), ("root_end", u32), ("background", u32),
-                ("off_nodes", u64), ("off_prims", u64), ("off_tri_verts", u64), ("off_tri_attrs", u64),
-                ("off_spheres", u64), ("off_moving_spheres", u64), ("off_rects", u64), ("off_xforms", u64),
+                ("off_nodes", u64), ("off_prims", u64), ("off_geom", u64), ("off_tri_attrs", u64),
+                ("reserved0", u64), ("reserved1", u64), ("reserved2", u64), ("off_xforms", u64),
                 ("off_materials", u64), ("off_textures", u64), ("off_texels", u64), ("off_lights", u64),
                 ("camera", Camera), ("bvh_seed", u64)]
 

@@ -68,90 +68,134 @@ struct LaneHit {
 };
 struct LaneCount { uint32_t box, tri, sph; };
 
-template <int LEVEL, bool COUNT>
+struct NodeS { double bmin[3], bmax[3]; uint32_t skip, flags, p0, p1; };  // one s_load_dwordx16
+RT_DEV NodeS load_node(cptr<rt_node> nodes, uint32_t i) {
+    const RT_CONST rt_node& n = nodes[i];
+    NodeS r;
+    r.bmin[0] = n.bmin[0]; r.bmin[1] = n.bmin[1]; r.bmin[2] = n.bmin[2];
+    r.bmax[0] = n.bmax[0]; r.bmax[1] = n.bmax[1]; r.bmax[2] = n.bmax[2];
+    r.skip = n.skip; r.flags = n.flags; r.p0 = n.prim0; r.p1 = n.prim1;
+    return r;
+}
+struct GeomS { double d[9]; uint32_t kind, xform; };  // 80 B: s_load_dwordx16 + x4
+RT_DEV GeomS load_geom(cptr<rt_geom> geom, uint32_t p) {
+    const RT_CONST rt_geom& g = geom[p];
+    GeomS r;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r.d[k] = g.d[k];
+    r.kind = g.kind; r.xform = g.xform;
+    return r;
+}
+
+template <int LEVEL, bool COUNT, bool INST>
 RT_DEV void traverse(const SceneDev& sc, uint32_t first, uint32_t end, d3 o, d3 d, double time, bool active, double t_min,
                      LaneHit& h, uint32_t inst_prim, LaneCount& cnt);
 
-template <int LEVEL, bool COUNT>
-RT_DEV void test_prim(const SceneDev& sc, uint32_t p, bool pass, d3 o, d3 d, double time, double t_min, LaneHit& h, uint32_t inst_prim,
+RT_DEV bool ray_is_plain(d3 o, d3 inv) {  // box_axis_fast precondition: no NaN can appear in (b - o) * inv
+    return isfinite(o.x) && isfinite(o.y) && isfinite(o.z) && isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z) && inv.x != 0.0 && inv.y != 0.0 && inv.z != 0.0;
+}
+
+template <int LEVEL, bool COUNT, bool INST>
+RT_DEV void test_prim(const SceneDev& sc, uint32_t p, const GeomS& g, bool pass, d3 o, d3 d, double time, double t_min, LaneHit& h, uint32_t inst_prim,
                       uint32_t& cached_xf, d3& xo, d3& xd, LaneCount& cnt) {
-    const RT_CONST rt_prim& pr = as_const(sc.prims)[p];  // wave-uniform -> scalar load
-    const uint32_t kind = pr.kind, index = pr.index, xf = pr.xform;
     d3 ro = o, rd = d;
-    if (xf != RT_NONE) {  // transform.rs:25-32; one transform per (ray, distinct matrix): the pagoda wraps every triangle in the same one
-        if (xf != cached_xf) {
-            cptr<double> m = as_const(sc.xforms[xf].t_inv);
+    if (g.xform != RT_NONE) {  // transform.rs:25-32; one transform per (ray, distinct matrix): the pagoda wraps every triangle in the same one
+        if (g.xform != cached_xf) {
+            cptr<double> m = as_const(sc.xforms[g.xform].t_inv);
             double mm[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) mm[k] = m[k];
             xo = mat_mul_xyz(mm, o, 1.0);
             xd = mat_mul_xyz(mm, d, 0.0);
-            cached_xf = xf;
+            cached_xf = g.xform;
         }
         ro = xo; rd = xd;
     }
     double t;
-    if (kind == RT_PRIM_TRIANGLE) {
-        const RT_CONST rt_tri_verts& tv = as_const(sc.tri_verts)[index];
-        d3 v0 = mk(tv.v0[0], tv.v0[1], tv.v0[2]), v1 = mk(tv.v1[0], tv.v1[1], tv.v1[2]), v2 = mk(tv.v2[0], tv.v2[1], tv.v2[2]);
-        double u, v;
+    if (g.kind == RT_PRIM_TRIANGLE) {
+        const d3 v0 = mk(g.d[0], g.d[1], g.d[2]), e1 = mk(g.d[3], g.d[4], g.d[5]), e2 = mk(g.d[6], g.d[7], g.d[8]);
         if (COUNT) cnt.tri += pass ? 1u : 0u;
-        if (pass && tri_hit(v0, v1, v2, ro, rd, t_min, h.best, t, u, v)) { h.best = t; h.prim = p; h.inst = inst_prim; }
-    } else if (kind == RT_PRIM_SPHERE) {
-        const RT_CONST rt_sphere& s = as_const(sc.spheres)[index];
+        TriStage st;
+        const bool alive = tri_stage_a(v0, e1, e2, ro, rd, st) & pass;
+        if (__ballot(alive) != 0ull) {  // rare: most tested triangles are nowhere near the ray
+            if (alive && tri_hit_tail(st, e1, e2, rd, t_min, h.best, t)) { h.best = t; h.prim = p; h.inst = inst_prim; }
+        }
+    } else if (g.kind == RT_PRIM_SPHERE) {
         if (COUNT) cnt.sph += pass ? 1u : 0u;
-        if (pass && sphere_hit(mk(s.center[0], s.center[1], s.center[2]), s.radius, ro, rd, t_min, h.best, t)) { h.best = t; h.prim = p; h.inst = inst_prim; }
-    } else if (kind == RT_PRIM_MOVING_SPHERE) {
-        const RT_CONST rt_moving_sphere& s = as_const(sc.moving)[index];
+        if (pass && sphere_hit(mk(g.d[0], g.d[1], g.d[2]), g.d[3], ro, rd, t_min, h.best, t)) { h.best = t; h.prim = p; h.inst = inst_prim; }
+    } else if (g.kind == RT_PRIM_MOVING_SPHERE) {
         if (COUNT) cnt.sph += pass ? 1u : 0u;
-        d3 c = moving_center(mk(s.center0[0], s.center0[1], s.center0[2]), mk(s.center1[0], s.center1[1], s.center1[2]), s.time0, s.time1, time);
-        if (pass && sphere_hit(c, s.radius, ro, rd, t_min, h.best, t)) { h.best = t; h.prim = p; h.inst = inst_prim; }
-    } else if (kind == RT_PRIM_AARECT) {
-        const RT_CONST rt_aarect& a = as_const(sc.rects)[index];
-        if (pass && rect_hit(a.x0, a.x1, a.y0, a.y1, a.z, ro, rd, t_min, h.best, t)) { h.best = t; h.prim = p; h.inst = inst_prim; }
-    } else if constexpr (LEVEL == 0) {  // RT_PRIM_INSTANCE: BVHNode object (optionally under a Transformed), main.rs:161-188
-        traverse<1, COUNT>(sc, index, pr.sub_end, ro, rd, time, pass, t_min, h, p, cnt);
+        d3 c = moving_center(mk(g.d[0], g.d[1], g.d[2]), mk(g.d[3], g.d[4], g.d[5]), g.d[6], g.d[7], time);
+        if (pass && sphere_hit(c, g.d[8], ro, rd, t_min, h.best, t)) { h.best = t; h.prim = p; h.inst = inst_prim; }
+    } else if (g.kind == RT_PRIM_AARECT) {
+        if (pass && rect_hit(g.d[0], g.d[1], g.d[2], g.d[3], g.d[4], ro, rd, t_min, h.best, t)) { h.best = t; h.prim = p; h.inst = inst_prim; }
+    } else if constexpr (LEVEL == 0 && INST) {  // RT_PRIM_INSTANCE: BVHNode object (optionally under a Transformed), main.rs:161-188
+        traverse<1, COUNT, INST>(sc, (uint32_t)g.d[0], (uint32_t)g.d[1], ro, rd, time, pass, t_min, h, p, cnt);
     }
 }
 
-template <int LEVEL, bool COUNT>
+// Wave-coherent walk of the threaded pre-order array [first, end).
+//   * `i` is the wave-uniform cursor; a lane takes part in node i iff its private `next` equals i.
+//   * A lane that fails the box of node j sets next = skip(j); because subtrees nest, any lane that is
+//     NOT active at node i has next >= skip(i).  Hence the wave goes to i+1 if any lane passed node i
+//     and to skip(i) otherwise -- no cross-lane reduction is needed.
+//   * Node i+1 is fetched (scalar load) while node i is being tested.
+template <int LEVEL, bool COUNT, bool INST>
 RT_DEV void traverse(const SceneDev& sc, uint32_t first, uint32_t end, d3 o, d3 d, double time, bool active, double t_min,
                      LaneHit& h, uint32_t inst_prim, LaneCount& cnt) {
     const d3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);  // bounding_box.rs:29
-    uint32_t next = active ? first : 0xFFFFFFFFu;          // per lane: the next node this ray must visit
-    uint32_t i = first;                                    // wave-uniform cursor
+    // min/max form of the slab test is exact unless a NaN can appear (zero / non-finite direction or origin): decided per wave
+    const bool plain = sc.boxes_finite && __ballot(active && !ray_is_plain(o, inv)) == 0ull && t_min == t_min;
+    uint32_t next = active ? first : 0xFFFFFFFFu;
+    uint32_t i = first;
     uint32_t cached_xf = RT_NONE;
     d3 xo = o, xd = d;
     cptr<rt_node> nodes = as_const(sc.nodes);
-    while (i < end) {
-        const RT_CONST rt_node& nd = nodes[i];
-        const uint32_t flags = nd.flags, skip = nd.skip, p0 = nd.prim0, p1 = nd.prim1;
+    cptr<rt_geom> geom = as_const(sc.geom);
+    if (i >= end) return;
+    const uint32_t last = sc.n_nodes - 1u;
+    NodeS nd = load_node(nodes, i);
+    for (;;) {
+        const uint32_t ip1 = i + 1u;
+        const NodeS nx = load_node(nodes, ip1 < last ? ip1 : last);  // speculative: the common successor
+        const uint32_t p0 = nd.p0, p1 = nd.p1, skip = nd.skip, flags = nd.flags;
         const bool act = next == i;
         bool pass = act;
         if (!(flags & RT_NODE_NO_BOX)) {
             if (COUNT) cnt.box += act ? 1u : 0u;
-            bool bx = box_axis(nd.bmin[0], nd.bmax[0], o.x, inv.x, t_min, h.best);
-            bool by = box_axis(nd.bmin[1], nd.bmax[1], o.y, inv.y, t_min, h.best);
-            bool bz = box_axis(nd.bmin[2], nd.bmax[2], o.z, inv.z, t_min, h.best);
+            bool bx, by, bz;
+            if (plain) {
+                bx = box_axis_fast(nd.bmin[0], nd.bmax[0], o.x, inv.x, t_min, h.best);
+                by = box_axis_fast(nd.bmin[1], nd.bmax[1], o.y, inv.y, t_min, h.best);
+                bz = box_axis_fast(nd.bmin[2], nd.bmax[2], o.z, inv.z, t_min, h.best);
+            } else {
+                bx = box_axis(nd.bmin[0], nd.bmax[0], o.x, inv.x, t_min, h.best);
+                by = box_axis(nd.bmin[1], nd.bmax[1], o.y, inv.y, t_min, h.best);
+                bz = box_axis(nd.bmin[2], nd.bmax[2], o.z, inv.z, t_min, h.best);
+            }
             pass = act & bx & by & bz;
         }
-        next = act ? (pass ? i + 1u : skip) : next;
-        if (p0 != RT_NONE && __ballot(pass) != 0ull) {
-            test_prim<LEVEL, COUNT>(sc, p0, pass, o, d, time, t_min, h, inst_prim, cached_xf, xo, xd, cnt);
-            if (p1 != RT_NONE) test_prim<LEVEL, COUNT>(sc, p1, pass, o, d, time, t_min, h, inst_prim, cached_xf, xo, xd, cnt);
+        next = act ? (pass ? ip1 : skip) : next;
+        const bool any = __ballot(pass) != 0ull;
+        if (p0 != RT_NONE && any) {
+            const GeomS g0 = load_geom(geom, p0);
+            test_prim<LEVEL, COUNT, INST>(sc, p0, g0, pass, o, d, time, t_min, h, inst_prim, cached_xf, xo, xd, cnt);
+            if (p1 != RT_NONE) {
+                const GeomS g1 = load_geom(geom, p1);
+                test_prim<LEVEL, COUNT, INST>(sc, p1, g1, pass, o, d, time, t_min, h, inst_prim, cached_xf, xo, xd, cnt);
+            }
             if (COUNT && (flags & RT_NODE_DUP_RIGHT)) {  // reference-order count of the skipped duplicate test
-                const uint32_t k = as_const(sc.prims)[p0].kind;
-                if (k == RT_PRIM_TRIANGLE) cnt.tri += pass ? 1u : 0u;
-                else if (k == RT_PRIM_SPHERE || k == RT_PRIM_MOVING_SPHERE) cnt.sph += pass ? 1u : 0u;
+                if (g0.kind == RT_PRIM_TRIANGLE) cnt.tri += pass ? 1u : 0u;
+                else if (g0.kind == RT_PRIM_SPHERE || g0.kind == RT_PRIM_MOVING_SPHERE) cnt.sph += pass ? 1u : 0u;
             }
         }
-        if (__ballot(next == i + 1u) != 0ull) i = i + 1u;
-        else i = wave_min_u32(next);
+        if (any) { i = ip1; if (i >= end) break; nd = nx; }
+        else { i = skip; if (i >= end) break; nd = load_node(nodes, i); }
     }
 }
 
 // rays: SoA [7][cap] (ox,oy,oz,dx,dy,dz,time) indexed by path; outputs indexed by path.
-template <bool COUNT>
+template <bool COUNT, bool INST>
 __global__ __launch_bounds__(256) void k_trace(SceneDev sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_fixed,
                                                const double* __restrict__ rays, uint32_t cap, double t_min, double t_max,
                                                uint32_t* __restrict__ out_prim, uint32_t* __restrict__ out_inst, double* __restrict__ out_t,
@@ -172,7 +216,7 @@ __global__ __launch_bounds__(256) void k_trace(SceneDev sc, const uint32_t* __re
     }
     LaneHit h; h.best = t_max; h.prim = RT_NONE; h.inst = RT_NONE;
     LaneCount cnt; cnt.box = cnt.tri = cnt.sph = 0;
-    traverse<0, COUNT>(sc, sc.root_node, sc.root_end, o, d, time, valid, t_min, h, RT_NONE, cnt);
+    traverse<0, COUNT, INST>(sc, sc.root_node, sc.root_end, o, d, time, valid, t_min, h, RT_NONE, cnt);
     if (valid) {
         out_prim[path] = h.prim;
         if (out_inst) out_inst[path] = h.inst;
@@ -470,6 +514,7 @@ struct rt_scene {
     SceneDev dev{};
     rt_blob_header hdr{};
     std::vector<rt_prim> host_prims;
+    bool has_instances = false;
     Workspace ws;
 };
 
@@ -535,8 +580,11 @@ static void launch_trace(rt_scene* sc, bool count, const uint32_t* queue, const 
                          double t_max, uint32_t* out_prim, uint32_t* out_inst, double* out_t) {
     hipStream_t st = sc->ctx->stream;
     if (n_bound == 0) return;
-    if (count) hipLaunchKernelGGL(k_trace<true>, grid_for(n_bound), dim3(256), 0, st, sc->dev, queue, n_ptr, n_bound, rays, sc->ws.cap, t_min, t_max, out_prim, out_inst, out_t, sc->ws.stats);
-    else hipLaunchKernelGGL(k_trace<false>, grid_for(n_bound), dim3(256), 0, st, sc->dev, queue, n_ptr, n_bound, rays, sc->ws.cap, t_min, t_max, out_prim, out_inst, out_t, sc->ws.stats);
+#define RT_LAUNCH_TRACE(C, I) hipLaunchKernelGGL((k_trace<C, I>), grid_for(n_bound), dim3(256), 0, st, sc->dev, queue, n_ptr, n_bound, rays, sc->ws.cap, t_min, t_max, out_prim, out_inst, out_t, sc->ws.stats)
+    const bool inst = sc->has_instances;  // scenes without BVHNode objects use the kernel variant compiled without the nested walk
+    if (count) { if (inst) RT_LAUNCH_TRACE(true, true); else RT_LAUNCH_TRACE(true, false); }
+    else { if (inst) RT_LAUNCH_TRACE(false, true); else RT_LAUNCH_TRACE(false, false); }
+#undef RT_LAUNCH_TRACE
 }
 
 // Runs the wavefront loop for n paths whose (pixel, sample) come either from explicit device lists
@@ -640,19 +688,21 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     if (h.total_bytes != nbytes) return fail(RT_ERR_BAD_BLOB, "blob size mismatch");
     // operand-shape checks: every index the kernels follow is validated here, on the host
     if (!range_ok(h.off_nodes, h.n_nodes, sizeof(rt_node), nbytes) || !range_ok(h.off_prims, h.n_prims, sizeof(rt_prim), nbytes) ||
-        !range_ok(h.off_tri_verts, h.n_tris, sizeof(rt_tri_verts), nbytes) || !range_ok(h.off_tri_attrs, h.n_tris, sizeof(rt_tri_attrs), nbytes) ||
-        !range_ok(h.off_spheres, h.n_spheres, sizeof(rt_sphere), nbytes) || !range_ok(h.off_moving_spheres, h.n_moving_spheres, sizeof(rt_moving_sphere), nbytes) ||
-        !range_ok(h.off_rects, h.n_rects, sizeof(rt_aarect), nbytes) || !range_ok(h.off_xforms, h.n_xforms, sizeof(rt_xform), nbytes) ||
+        !range_ok(h.off_geom, h.n_prims, sizeof(rt_geom), nbytes) || !range_ok(h.off_tri_attrs, h.n_tris, sizeof(rt_tri_attrs), nbytes) ||
+        !range_ok(h.off_xforms, h.n_xforms, sizeof(rt_xform), nbytes) ||
         !range_ok(h.off_materials, h.n_materials, sizeof(rt_material), nbytes) || !range_ok(h.off_textures, h.n_textures, sizeof(rt_texture), nbytes) ||
         !range_ok(h.off_texels, h.n_texel_bytes, 1, nbytes) || !range_ok(h.off_lights, h.n_lights, sizeof(rt_light), nbytes))
         return fail(RT_ERR_BAD_BLOB, "table offset/size out of range");
     const uint8_t* b = (const uint8_t*)blob;
     const rt_node* nodes = (const rt_node*)(b + h.off_nodes);
     const rt_prim* prims = (const rt_prim*)(b + h.off_prims);
+    const rt_geom* geom = (const rt_geom*)(b + h.off_geom);
     const rt_material* mats = (const rt_material*)(b + h.off_materials);
     const rt_texture* tex = (const rt_texture*)(b + h.off_textures);
     if (h.root_node > h.root_end || h.root_end > h.n_nodes) return fail(RT_ERR_BAD_BLOB, "root range out of bounds");
+    bool boxes_finite = true;
     for (uint32_t i = 0; i < h.n_nodes; ++i) {
+        for (int k = 0; k < 3; ++k) boxes_finite = boxes_finite && std::isfinite(nodes[i].bmin[k]) && std::isfinite(nodes[i].bmax[k]);
         if (nodes[i].skip <= i || nodes[i].skip > h.n_nodes) return fail(RT_ERR_BAD_BLOB, "node skip link not strictly forward / out of range");
         if ((nodes[i].prim0 != RT_NONE && nodes[i].prim0 >= h.n_prims) || (nodes[i].prim1 != RT_NONE && nodes[i].prim1 >= h.n_prims))
             return fail(RT_ERR_BAD_BLOB, "node primitive index out of range");
@@ -660,9 +710,12 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     }
     for (uint32_t i = 0; i < h.n_prims; ++i) {
         const rt_prim& p = prims[i];
-        uint32_t lim = p.kind == RT_PRIM_TRIANGLE ? h.n_tris : p.kind == RT_PRIM_SPHERE ? h.n_spheres : p.kind == RT_PRIM_MOVING_SPHERE ? h.n_moving_spheres
-                     : p.kind == RT_PRIM_AARECT ? h.n_rects : p.kind == RT_PRIM_INSTANCE ? h.n_nodes : 0;
-        if (p.kind > RT_PRIM_INSTANCE || p.index >= lim) return fail(RT_ERR_BAD_BLOB, "primitive kind/index out of range");
+        if (p.kind > RT_PRIM_INSTANCE) return fail(RT_ERR_BAD_BLOB, "primitive kind out of range");
+        if ((p.kind == RT_PRIM_TRIANGLE && p.index >= h.n_tris) || (p.kind == RT_PRIM_INSTANCE && p.index >= h.n_nodes))
+            return fail(RT_ERR_BAD_BLOB, "primitive index out of range");
+        if (geom[i].kind != p.kind || geom[i].xform != p.xform) return fail(RT_ERR_BAD_BLOB, "geom record does not match its primitive");
+        if (p.kind == RT_PRIM_INSTANCE && (geom[i].d[0] != (double)p.index || geom[i].d[1] != (double)p.sub_end))
+            return fail(RT_ERR_BAD_BLOB, "instance geom range does not match its primitive");
         if (p.xform != RT_NONE && p.xform >= h.n_xforms) return fail(RT_ERR_BAD_BLOB, "primitive xform out of range");
         if (p.kind == RT_PRIM_INSTANCE) {
             if (p.sub_end <= p.index || p.sub_end > h.n_nodes || p.index < h.root_end) return fail(RT_ERR_BAD_BLOB, "instance sub-array out of range");
@@ -708,6 +761,7 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     if (!sc) return fail(RT_ERR_OOM, "host allocation failed");
     sc->ctx = ctx; sc->hdr = h;
     sc->host_prims.assign(prims, prims + h.n_prims);
+    for (uint32_t i = 0; i < h.n_prims; ++i) sc->has_instances = sc->has_instances || prims[i].kind == RT_PRIM_INSTANCE;
     hipError_t e = hipMalloc(&sc->dblob, nbytes);
     if (e == hipSuccess) e = hipMalloc((void**)&sc->d_mat_uses_uv, uses_uv.size());
     if (e == hipSuccess) e = hipMemcpy(sc->dblob, blob, nbytes, hipMemcpyHostToDevice);
@@ -721,12 +775,12 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     const uint8_t* d = (const uint8_t*)sc->dblob;
     SceneDev& v = sc->dev;
     v.nodes = (const rt_node*)(d + h.off_nodes); v.prims = (const rt_prim*)(d + h.off_prims);
-    v.tri_verts = (const rt_tri_verts*)(d + h.off_tri_verts); v.tri_attrs = (const rt_tri_attrs*)(d + h.off_tri_attrs);
-    v.spheres = (const rt_sphere*)(d + h.off_spheres); v.moving = (const rt_moving_sphere*)(d + h.off_moving_spheres);
-    v.rects = (const rt_aarect*)(d + h.off_rects); v.xforms = (const rt_xform*)(d + h.off_xforms);
+    v.geom = (const rt_geom*)(d + h.off_geom); v.tri_attrs = (const rt_tri_attrs*)(d + h.off_tri_attrs);
+    v.xforms = (const rt_xform*)(d + h.off_xforms);
     v.materials = (const rt_material*)(d + h.off_materials); v.textures = (const rt_texture*)(d + h.off_textures);
     v.texels = d + h.off_texels; v.lights = (const rt_light*)(d + h.off_lights);
     v.mat_uses_uv = sc->d_mat_uses_uv;
+    v.n_nodes = h.n_nodes; v.boxes_finite = boxes_finite ? 1u : 0u;
     v.camera = h.camera; v.n_lights = h.n_lights; v.root_node = h.root_node; v.root_end = h.root_end; v.background = h.background;
     *out = sc;
     return RT_OK;

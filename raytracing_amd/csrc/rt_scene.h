@@ -18,11 +18,8 @@ template <class T> RT_DEV cptr<T> as_const(const T* p) { return (cptr<T>)(uintpt
 struct SceneDev {
     const rt_node* nodes;
     const rt_prim* prims;
-    const rt_tri_verts* tri_verts;
+    const rt_geom* geom;  // parallel to prims
     const rt_tri_attrs* tri_attrs;
-    const rt_sphere* spheres;
-    const rt_moving_sphere* moving;
-    const rt_aarect* rects;
     const rt_xform* xforms;
     const rt_material* materials;
     const rt_texture* textures;
@@ -31,6 +28,7 @@ struct SceneDev {
     const uint8_t* mat_uses_uv;
     rt_camera camera;
     uint32_t n_lights, root_node, root_end, background;
+    uint32_t n_nodes, boxes_finite;
 };
 
 // ---- bounding_box.rs:27-46, literal: three independent per-axis tests against the ORIGINAL
@@ -46,10 +44,23 @@ RT_DEV bool box_axis(double bmin, double bmax, double o, double inv, double t_mi
     return !(hi < lo);
 }
 
+// Same test with v_min/v_max (9 instead of 13 VALU ops per axis).  Bit-for-bit the same decision as
+// box_axis whenever t0 and t1 are not NaN: min/max reproduce the swap, and `a > t_min ? a : t_min`
+// == max(a, t_min) for non-NaN a (comparisons ignore the sign of zero).  t0/t1 cannot be NaN when the
+// box, the origin and 1/dir are finite and 1/dir != 0 -- the kernel checks that per wave and
+// falls back to box_axis otherwise.
+RT_DEV bool box_axis_fast(double bmin, double bmax, double o, double inv, double t_min, double t_max) {
+    double t0 = (bmin - o) * inv;
+    double t1 = (bmax - o) * inv;
+    double lo = fmax(fmin(t0, t1), t_min);
+    double hi = fmin(fmax(t0, t1), t_max);
+    return !(hi < lo);
+}
+
 // ---- primitive tests: return true and t when the reference's `hit` returns Some --------------
 // mesh.rs:48-81 (Moller-Trumbore, two-sided, exact statement order)
-RT_DEV bool tri_hit(d3 v0, d3 v1, d3 v2, d3 o, d3 d, double t_min, double t_max, double& t_out, double& u_out, double& v_out) {
-    d3 edge1 = v1 - v0, edge2 = v2 - v0;
+// edge1 = v1 - v0 and edge2 = v2 - v0 (mesh.rs:55-56) come precomputed from the host (rt_geom)
+RT_DEV bool tri_hit(d3 v0, d3 edge1, d3 edge2, d3 o, d3 d, double t_min, double t_max, double& t_out, double& u_out, double& v_out) {
     d3 h = cross(d, edge2);
     double det = dot(edge1, h);
     if (det > -F64_EPS && det < F64_EPS) return false;
@@ -63,6 +74,39 @@ RT_DEV bool tri_hit(d3 v0, d3 v1, d3 v2, d3 o, d3 d, double t_min, double t_max,
     double t = det_inv * dot(edge2, q);
     if (t <= F64_EPS || t > t_max || t <= t_min) return false;
     t_out = t; u_out = u; v_out = v;
+    return true;
+}
+// Wave-friendly staging of the same test.  Stage A computes the reference's own h, det, s and s.h
+// (same operations, same order) and applies a CONSERVATIVE rejection that is implied by the
+// reference's `u` test, so the 1/det division and the rest run only for lanes that may still hit:
+//   |det| in [EPS, 1e280]  =>  det_inv = RN(1/det) is normal with relative error <= 2^-53, and
+//   (R1) s.h and det of opposite sign with |s.h| >= 1e-20  =>  u = RN(det_inv * s.h) is a negative
+//        normal number  =>  `u >= 0` fails;
+//   (R2) |s.h| > RN(|det| * (1 + 2^-40))  =>  |det_inv * s.h| > (1 + 2^-41)(1 - 2^-53) > 1  =>  u < 0 or u > 1.
+// Everything not rejected here is decided by the literal code of tri_hit_tail.
+struct TriStage { d3 h, s; double det, sh; };
+RT_DEV bool tri_stage_a(d3 v0, d3 edge1, d3 edge2, d3 o, d3 d, TriStage& st) {
+    st.h = cross(d, edge2);
+    st.det = dot(edge1, st.h);
+    st.s = o - v0;
+    st.sh = dot(st.s, st.h);
+    const double ad = fabs(st.det), as = fabs(st.sh);
+    if (st.det > -F64_EPS && st.det < F64_EPS) return false;                       // mesh.rs:59-61
+    const bool in_range = ad <= 1e280;
+    const bool r2 = as > ad * 1.0000000000009094947;                               // 1 + 2^-40
+    const bool r1 = ((st.sh < 0.0) != (st.det < 0.0)) && as >= 1e-20;
+    return !(in_range && (r1 || r2));
+}
+RT_DEV bool tri_hit_tail(const TriStage& st, d3 edge1, d3 edge2, d3 d, double t_min, double t_max, double& t_out) {
+    double det_inv = 1.0 / st.det;
+    double u = det_inv * st.sh;
+    if (!(u >= 0.0 && u <= 1.0)) return false;
+    d3 q = cross(st.s, edge1);
+    double v = det_inv * dot(d, q);
+    if (v < 0.0 || (u + v) > 1.0) return false;
+    double t = det_inv * dot(edge2, q);
+    if (t <= F64_EPS || t > t_max || t <= t_min) return false;
+    t_out = t;
     return true;
 }
 // shape.rs:93-121
@@ -119,6 +163,7 @@ RT_DEV bool material_uses_uv(const SceneDev& sc, uint32_t material);
 // on the same (possibly transformed) ray with t_max = t, which reproduces the same root / (u,v).
 RT_DEV bool full_hit(const SceneDev& sc, uint32_t prim, uint32_t inst, const Ray& ray, double t_min, double t_hit, HitRecord& hr) {
     rt_prim p = sc.prims[prim];
+    const rt_geom& g = sc.geom[prim];
     uint32_t xf = p.xform;
     if (inst != RT_NONE) xf = sc.prims[inst].xform;
     Ray r = ray;
@@ -131,9 +176,8 @@ RT_DEV bool full_hit(const SceneDev& sc, uint32_t prim, uint32_t inst, const Ray
     hr.material = p.material;
     double t = 0.0;
     if (p.kind == RT_PRIM_TRIANGLE) {
-        const rt_tri_verts& tv = sc.tri_verts[p.index];
         double u, v;
-        if (!tri_hit(ld3(tv.v0), ld3(tv.v1), ld3(tv.v2), r.o, r.d, t_min, t_hit, t, u, v)) return false;
+        if (!tri_hit(ld3(g.d), ld3(g.d + 3), ld3(g.d + 6), r.o, r.d, t_min, t_hit, t, u, v)) return false;
         const rt_tri_attrs& ta = sc.tri_attrs[p.index];
         double w = 1.0 - (u + v);
         hr.normal = ((u * ld3(ta.n0)) + (v * ld3(ta.n1))) + (w * ld3(ta.n2));  // mesh.rs:95: u weights vertex 0 (reference quirk)
@@ -143,8 +187,8 @@ RT_DEV bool full_hit(const SceneDev& sc, uint32_t prim, uint32_t inst, const Ray
         hr.front_face = dot(r.d, hr.normal) > 0.0;  // mesh.rs:105
     } else if (p.kind == RT_PRIM_SPHERE || p.kind == RT_PRIM_MOVING_SPHERE) {
         d3 center; double radius;
-        if (p.kind == RT_PRIM_SPHERE) { const rt_sphere& s = sc.spheres[p.index]; center = ld3(s.center); radius = s.radius; }
-        else { const rt_moving_sphere& s = sc.moving[p.index]; center = moving_center(ld3(s.center0), ld3(s.center1), s.time0, s.time1, r.time); radius = s.radius; }
+        if (p.kind == RT_PRIM_SPHERE) { center = ld3(g.d); radius = g.d[3]; }
+        else { center = moving_center(ld3(g.d), ld3(g.d + 3), g.d[6], g.d[7], r.time); radius = g.d[8]; }
         if (!sphere_hit(center, radius, r.o, r.d, t_min, t_hit, t)) return false;
         hr.point = ray_at(r, t);
         d3 normal = (hr.point - center) / radius;
@@ -152,11 +196,11 @@ RT_DEV bool full_hit(const SceneDev& sc, uint32_t prim, uint32_t inst, const Ray
         if (material_uses_uv(sc, p.material)) spherical_uv(normal, hr.u, hr.v);  // (u,v) only feed image textures
         set_face_normal(hr, r.d, normal);
     } else {  // RT_PRIM_AARECT, shape.rs:280-295
-        const rt_aarect& a = sc.rects[p.index];
-        if (!rect_hit(a.x0, a.x1, a.y0, a.y1, a.z, r.o, r.d, t_min, t_hit, t)) return false;
+        const double x0 = g.d[0], x1 = g.d[1], y0 = g.d[2], y1 = g.d[3];
+        if (!rect_hit(x0, x1, y0, y1, g.d[4], r.o, r.d, t_min, t_hit, t)) return false;
         hr.point = ray_at(r, t);
-        hr.u = (hr.point.x - a.x0) / (a.x1 - a.x0);
-        hr.v = (hr.point.y - a.y0) / (a.y1 - a.y0);
+        hr.u = (hr.point.x - x0) / (x1 - x0);
+        hr.v = (hr.point.y - y0) / (y1 - y0);
         set_face_normal(hr, r.d, mk(0.0, 0.0, 1.0));
     }
     hr.t = t;

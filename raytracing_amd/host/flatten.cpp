@@ -172,8 +172,8 @@ namespace {
 struct Flattener {
     Tables tb;
     std::vector<rt_node> nodes; std::vector<rt_prim> prims;
-    std::vector<rt_tri_verts> tri_verts; std::vector<rt_tri_attrs> tri_attrs;
-    std::vector<rt_sphere> spheres; std::vector<rt_moving_sphere> moving; std::vector<rt_aarect> rects;
+    std::vector<rt_geom> geom; std::vector<rt_tri_attrs> tri_attrs;
+    uint32_t n_spheres = 0, n_moving = 0, n_rects = 0;
     std::vector<uint8_t> texels; std::vector<uint32_t> tex_offset;
     struct PendingInstance { const BVHNode* bvh; std::vector<uint32_t> prim_slots; };
     std::vector<PendingInstance> pending; std::unordered_map<const BVHNode*, size_t> pending_of;
@@ -190,27 +190,30 @@ struct Flattener {
             return make_prim(x->hittable.get(), tb.xform(x->t), tb.obj_id.at(h), under_instance_xform);
         }
         p.object_id = tb.obj_id.at(h);
+        rt_geom g; memset(&g, 0, sizeof g);
         if (auto s = dynamic_cast<const Sphere*>(h)) {
-            p.kind = RT_PRIM_SPHERE; p.index = (uint32_t)spheres.size(); p.material = tb.mat_id.at(s->material.get());
-            rt_sphere r; v3(r.center, s->center); r.radius = s->radius; spheres.push_back(r);
+            p.kind = RT_PRIM_SPHERE; p.material = tb.mat_id.at(s->material.get()); ++n_spheres;
+            v3(g.d, s->center); g.d[3] = s->radius;
         } else if (auto ms = dynamic_cast<const MovingSphere*>(h)) {
-            p.kind = RT_PRIM_MOVING_SPHERE; p.index = (uint32_t)moving.size(); p.material = tb.mat_id.at(ms->material.get());
-            rt_moving_sphere r; v3(r.center0, ms->center_0); v3(r.center1, ms->center_1); r.time0 = ms->time_0; r.time1 = ms->time_1; r.radius = ms->radius; moving.push_back(r);
+            p.kind = RT_PRIM_MOVING_SPHERE; p.material = tb.mat_id.at(ms->material.get()); ++n_moving;
+            v3(g.d, ms->center_0); v3(g.d + 3, ms->center_1); g.d[6] = ms->time_0; g.d[7] = ms->time_1; g.d[8] = ms->radius;
         } else if (auto a = dynamic_cast<const AARect*>(h)) {
-            p.kind = RT_PRIM_AARECT; p.index = (uint32_t)rects.size(); p.material = tb.mat_id.at(a->material.get());
-            rects.push_back(rt_aarect{a->x_range.first, a->x_range.second, a->y_range.first, a->y_range.second, a->z});
+            p.kind = RT_PRIM_AARECT; p.material = tb.mat_id.at(a->material.get()); ++n_rects;
+            g.d[0] = a->x_range.first; g.d[1] = a->x_range.second; g.d[2] = a->y_range.first; g.d[3] = a->y_range.second; g.d[4] = a->z;
         } else if (auto t = dynamic_cast<const Triangle*>(h)) {
             const Mesh* me = t->data.get();
-            p.kind = RT_PRIM_TRIANGLE; p.index = (uint32_t)tri_verts.size(); p.material = tb.mat_id.at(me->material.get());
-            rt_tri_verts tv; rt_tri_attrs ta; memset(&ta, 0, sizeof ta);
-            double* vv[3] = {tv.v0, tv.v1, tv.v2}; double* nn[3] = {ta.n0, ta.n1, ta.n2}; double* uu[3] = {ta.uv0, ta.uv1, ta.uv2};
+            p.kind = RT_PRIM_TRIANGLE; p.index = (uint32_t)tri_attrs.size(); p.material = tb.mat_id.at(me->material.get());
+            rt_tri_attrs ta; memset(&ta, 0, sizeof ta);
+            double* nn[3] = {ta.n0, ta.n1, ta.n2}; double* uu[3] = {ta.uv0, ta.uv1, ta.uv2};
+            DVec3 vv[3];
             for (int k = 0; k < 3; ++k) {
                 uint32_t i = t->indices[k];
-                v3(vv[k], me->vertices.at(i));
+                vv[k] = me->vertices.at(i);
                 if (i < me->normals.size()) v3(nn[k], me->normals[i]);
                 if (i < me->uv.size()) { uu[k][0] = me->uv[i].x; uu[k][1] = me->uv[i].y; }
             }
-            tri_verts.push_back(tv); tri_attrs.push_back(ta);
+            v3(g.d, vv[0]); v3(g.d + 3, vv[1] - vv[0]); v3(g.d + 6, vv[2] - vv[0]);  // edge1, edge2 of mesh.rs:55-56
+            tri_attrs.push_back(ta);
         } else if (auto b = dynamic_cast<const BVHNode*>(h)) {
             if (inside_instance) throw Unsupported("BVHNode object nested inside another BVHNode object");
             p.kind = RT_PRIM_INSTANCE;
@@ -219,6 +222,8 @@ struct Flattener {
             if (it == pending_of.end()) { k = pending.size(); pending.push_back({b, {}}); pending_of[b] = k; } else k = it->second;
             pending[k].prim_slots.push_back((uint32_t)prims.size());
         } else throw Unsupported("unknown Hittable implementation");
+        g.kind = p.kind; g.xform = p.xform;
+        geom.push_back(g);
         prims.push_back(p);
         return (uint32_t)prims.size() - 1;
     }
@@ -272,7 +277,7 @@ struct Flattener {
             uint32_t first = (uint32_t)nodes.size();
             emit_bvh(pending[k].bvh, any_xf);
             uint32_t end = (uint32_t)nodes.size();
-            for (uint32_t slot : pending[k].prim_slots) { prims[slot].index = first; prims[slot].sub_end = end; }
+            for (uint32_t slot : pending[k].prim_slots) { prims[slot].index = first; prims[slot].sub_end = end; geom[slot].d[0] = (double)first; geom[slot].d[1] = (double)end; }
         }
         // materials / textures / lights
         std::vector<rt_texture> tex(tb.textures.size());
@@ -311,8 +316,8 @@ struct Flattener {
         }
         rt_blob_header h; memset(&h, 0, sizeof h);
         h.magic = RT_BLOB_MAGIC; h.version = RT_BLOB_VERSION;
-        h.n_nodes = (uint32_t)nodes.size(); h.n_prims = (uint32_t)prims.size(); h.n_tris = (uint32_t)tri_verts.size();
-        h.n_spheres = (uint32_t)spheres.size(); h.n_moving_spheres = (uint32_t)moving.size(); h.n_rects = (uint32_t)rects.size();
+        h.n_nodes = (uint32_t)nodes.size(); h.n_prims = (uint32_t)prims.size(); h.n_tris = (uint32_t)tri_attrs.size();
+        h.n_spheres = n_spheres; h.n_moving_spheres = n_moving; h.n_rects = n_rects;
         h.n_xforms = (uint32_t)xf.size(); h.n_materials = (uint32_t)mats.size(); h.n_textures = (uint32_t)tex.size(); h.n_lights = (uint32_t)lights.size();
         h.n_texel_bytes = (uint32_t)texels.size();
         h.root_node = root; h.root_end = root_end; h.background = (uint32_t)sc.background; h.bvh_seed = tb.seed;
@@ -321,8 +326,8 @@ struct Flattener {
         v3(h.camera.vertical, c.vertical); v3(h.camera.u, c.u); v3(h.camera.v, c.v);
         h.camera.lens_radius = c.lens_radius; h.camera.time0 = c.time_0; h.camera.time1 = c.time_1;
         std::vector<uint8_t> out(sizeof h, 0);
-        h.off_nodes = append(out, nodes); h.off_prims = append(out, prims); h.off_tri_verts = append(out, tri_verts); h.off_tri_attrs = append(out, tri_attrs);
-        h.off_spheres = append(out, spheres); h.off_moving_spheres = append(out, moving); h.off_rects = append(out, rects); h.off_xforms = append(out, xf);
+        h.off_nodes = append(out, nodes); h.off_prims = append(out, prims); h.off_geom = append(out, geom); h.off_tri_attrs = append(out, tri_attrs);
+        h.off_xforms = append(out, xf);
         h.off_materials = append(out, mats); h.off_textures = append(out, tex); h.off_texels = append(out, texels); h.off_lights = append(out, lights);
         while (out.size() % 16) out.push_back(0);
         h.total_bytes = out.size();

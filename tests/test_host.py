@@ -43,7 +43,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_ffi.Node) == 64 and C.sizeof(_ffi.Prim) == 32 and C.sizeof(_ffi.Camera) == 21 * 8
     hs = rt.HostScene.builtin("simple_triangle")
     h = hs.header()
-    assert h.magic == 0x42535452 and h.version == 1 and h.total_bytes == len(hs.blob())
+    assert h.magic == 0x42535452 and h.version == 2 and h.total_bytes == len(hs.blob())
 
 
 def _obj_of(prims, p):
