@@ -16,6 +16,7 @@
 //   sub-path radiance, integrator.rs:119-136, so a running throughput cannot express it).
 #include "rt_scene.h"
 #include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -277,6 +278,34 @@ struct PathBuffers {
     uint32_t cap;
 };
 
+// Coherence key of a secondary ray: direction octant (3 bits) | Morton code of the origin cell
+// (5 bits per axis over the scene box).  The reference's per-axis slab test makes the visited node
+// set a function of "which boxes lie ahead of the origin on each axis", i.e. of octant and origin:
+// rays with equal keys walk nearly the same nodes, so a wave of them wastes few lanes.
+RT_DEV uint32_t spread5(uint32_t v) { v &= 31u; v = (v | (v << 8)) & 0x100Fu; v = (v | (v << 4)) & 0x10C3u; v = (v | (v << 2)) & 0x1249u; return v; }
+RT_DEV uint32_t sort_key(const SceneDev& sc, d3 o, d3 d) {
+    const uint32_t oct = (d.x < 0.0 ? 1u : 0u) | (d.y < 0.0 ? 2u : 0u) | (d.z < 0.0 ? 4u : 0u);
+    const float fx = ((float)o.x - sc.sort_min[0]) * sc.sort_scale[0], fy = ((float)o.y - sc.sort_min[1]) * sc.sort_scale[1], fz = ((float)o.z - sc.sort_min[2]) * sc.sort_scale[2];
+    const uint32_t cx = (uint32_t)fminf(fmaxf(fx, 0.f), 31.f), cy = (uint32_t)fminf(fmaxf(fy, 0.f), 31.f), cz = (uint32_t)fminf(fmaxf(fz, 0.f), 31.f);
+    return (oct << 15) | spread5(cx) | (spread5(cy) << 1) | (spread5(cz) << 2);
+}
+#define RT_SORT_BITS 19u  /* 18 key bits + bit 18 = "empty slot" (slots are pre-filled with 0xFFFFFFFF) */
+
+RT_DEV void push_queue_keyed(bool want, uint32_t path, uint32_t key, uint32_t* __restrict__ queue, uint32_t* __restrict__ keys, uint32_t* __restrict__ count) {
+    const uint64_t m = __ballot(want);
+    if (m == 0ull) return;
+    uint32_t base = 0;
+    const uint32_t lane = lane_id();
+    const uint32_t leader = (uint32_t)__builtin_ctzll(m);
+    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, (int)leader, 64);
+    if (want) {
+        const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        queue[slot] = path;
+        if (keys) keys[slot] = key;
+    }
+}
+
 RT_DEV void push_queue(bool want, uint32_t path, uint32_t* __restrict__ queue, uint32_t* __restrict__ count) {
     const uint64_t m = __ballot(want);
     if (m == 0ull) return;
@@ -290,15 +319,15 @@ RT_DEV void push_queue(bool want, uint32_t path, uint32_t* __restrict__ queue, u
 
 __global__ __launch_bounds__(256) void k_shade(SceneDev sc, PathBuffers pb, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr,
                                                uint32_t bounce, int32_t max_depth, int32_t integrator, uint64_t seed,
-                                               uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_count,
-                                               uint32_t* __restrict__ shadow_queue, uint32_t* __restrict__ shadow_count) {
+                                               uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_keys, uint32_t* __restrict__ next_count,
+                                               uint32_t* __restrict__ shadow_queue, uint32_t* __restrict__ shadow_keys, uint32_t* __restrict__ shadow_count) {
     const uint32_t n = *n_ptr;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if ((gid & ~63u) >= n) return;
     const bool valid = gid < n;
     const uint32_t cap = pb.cap;
     bool want_next = false, want_shadow = false;
-    uint32_t path = 0;
+    uint32_t path = 0, next_key = 0, shadow_key = 0;
     if (valid) {
         path = queue[gid];
         Ray ray;
@@ -367,6 +396,7 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, PathBuffers pb, cons
                             pb.shadow_rays[3 * (size_t)cap + path] = light_dir.x; pb.shadow_rays[4 * (size_t)cap + path] = light_dir.y; pb.shadow_rays[5 * (size_t)cap + path] = light_dir.z;
                             pb.shadow_rays[6 * (size_t)cap + path] = ray.time;
                             want_shadow = true;
+                            shadow_key = sort_key(sc, hr.point, light_dir);
                         }
                     }
                 } else if (integrator == RT_INT_LIGHT_IS) {  // integrator.rs:187-224 (emitted == 0 here)
@@ -399,14 +429,15 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, PathBuffers pb, cons
                         pb.rays[0 * (size_t)cap + path] = hr.point.x; pb.rays[1 * (size_t)cap + path] = hr.point.y; pb.rays[2 * (size_t)cap + path] = hr.point.z;
                         pb.rays[3 * (size_t)cap + path] = out_dir.x; pb.rays[4 * (size_t)cap + path] = out_dir.y; pb.rays[5 * (size_t)cap + path] = out_dir.z;
                         want_next = true;
+                        next_key = sort_key(sc, hr.point, out_dir);
                     }
                 }
             }
         }
         if (done) { pb.terminal[0 * (size_t)cap + path] = terminal.x; pb.terminal[1 * (size_t)cap + path] = terminal.y; pb.terminal[2 * (size_t)cap + path] = terminal.z; }
     }
-    push_queue(want_next, path, next_queue, next_count);
-    push_queue(want_shadow, path, shadow_queue, shadow_count);
+    push_queue_keyed(want_next, path, next_key, next_queue, next_keys, next_count);
+    push_queue_keyed(want_shadow, path, shadow_key, shadow_queue, shadow_keys, shadow_count);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -503,6 +534,8 @@ struct Workspace {
     uint32_t* counts = nullptr;  // [0],[1]: path queue counts; [2]: shadow count
     unsigned long long* stats = nullptr;  // rays, box, tri, sph
     uint32_t* in_pixel = nullptr; uint32_t* in_sample = nullptr;
+    uint32_t* raw_queue = nullptr; uint32_t* raw_keys = nullptr; uint32_t* raw_squeue = nullptr; uint32_t* raw_skeys = nullptr; uint32_t* sorted_keys = nullptr;  // ray sorting
+    void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     uint32_t cap = 0; int32_t depth = 0;
     std::vector<void*> allocs;
 };
@@ -515,6 +548,7 @@ struct rt_scene {
     rt_blob_header hdr{};
     std::vector<rt_prim> host_prims;
     bool has_instances = false;
+    bool sortable = false;  // scene has a finite box to quantise ray origins against
     Workspace ws;
 };
 
@@ -543,6 +577,15 @@ static int ws_ensure(rt_scene* sc, uint32_t cap, int32_t depth) {
     WS(ws.pb.records, (size_t)std::max(depth, 1) * REC_FIELDS * cap)
     WS(ws.queue[0], cap) WS(ws.queue[1], cap) WS(ws.shadow_queue, cap) WS(ws.counts, 4) WS(ws.stats, 4)
     WS(ws.in_pixel, cap) WS(ws.in_sample, cap)
+    WS(ws.raw_queue, cap) WS(ws.raw_keys, cap) WS(ws.raw_squeue, cap) WS(ws.raw_skeys, cap) WS(ws.sorted_keys, cap)
+    {
+        size_t bytes = 0;
+        hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, ws.raw_keys, ws.sorted_keys, ws.raw_queue, ws.queue[0], (size_t)cap, 0u, RT_SORT_BITS, sc->ctx->stream);
+        if (e != hipSuccess) { ws_free(ws); return fail(RT_ERR_HIP, std::string("rocprim size query: ") + hipGetErrorString(e)); }
+        uint8_t* tmp = nullptr;
+        WS(tmp, bytes)
+        ws.sort_tmp = tmp; ws.sort_tmp_bytes = bytes;
+    }
 #undef WS
     ws.pb.cap = cap; ws.cap = cap; ws.depth = depth;
     return RT_OK;
@@ -589,8 +632,16 @@ static void launch_trace(rt_scene* sc, bool count, const uint32_t* queue, const 
 
 // Runs the wavefront loop for n paths whose (pixel, sample) come either from explicit device lists
 // (ws.in_pixel / ws.in_sample) or from the frame formula; leaves per-path radiance in ws.pb.radiance.
+// stable LSD radix sort of (key, path) over the n slots of a queue; empty slots carry 0xFFFFFFFF and end up last
+static int sort_queue(rt_scene* sc, uint32_t n, uint32_t* keys_in, uint32_t* queue_in, uint32_t* out_queue) {
+    Workspace& ws = sc->ws;
+    size_t bytes = ws.sort_tmp_bytes;
+    HIP_OK(rocprim::radix_sort_pairs(ws.sort_tmp, bytes, keys_in, ws.sorted_keys, queue_in, out_queue, (size_t)n, 0u, RT_SORT_BITS, sc->ctx->stream));
+    return RT_OK;
+}
+
 static int run_paths(rt_scene* sc, uint32_t n, bool explicit_lists, uint32_t width, uint32_t height, uint32_t sample0, int32_t max_depth,
-                     int32_t integrator, uint64_t seed, bool count_tests, EventTimer& tm, uint64_t& launches) {
+                     int32_t integrator, uint64_t seed, bool count_tests, bool sort_rays, EventTimer& tm, uint64_t& launches) {
     Workspace& ws = sc->ws;
     hipStream_t st = sc->ctx->stream;
     const uint32_t npix = width * height;
@@ -610,12 +661,26 @@ static int run_paths(rt_scene* sc, uint32_t n, bool explicit_lists, uint32_t wid
         tm.begin(CAT_TRACE);
         launch_trace(sc, count_tests, ws.queue[cur], ws.counts + cur, n, ws.pb.rays, 0.001, 100000.0, ws.pb.hit_prim, ws.pb.hit_inst, ws.pb.hit_t);  // integrator.rs:38
         tm.end();
+        const bool mis_shadow = integrator == RT_INT_MIS && sc->dev.n_lights > 0;
+        const bool last_bounce = bounce + 1 >= max_depth;
         tm.begin(CAT_SHADE);
-        hipLaunchKernelGGL(k_shade, grid_for(n), dim3(256), 0, st, sc->dev, ws.pb, ws.queue[cur], ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
-                           seed, ws.queue[nxt], ws.counts + nxt, ws.shadow_queue, ws.counts + 2);
+        if (sort_rays) {
+            // shade appends survivors and their coherence keys to the raw queues; the sorted order lands in queue[nxt] / shadow_queue
+            HIP_OK(hipMemsetAsync(ws.raw_keys, 0xFF, (size_t)n * sizeof(uint32_t), st));
+            if (mis_shadow) HIP_OK(hipMemsetAsync(ws.raw_skeys, 0xFF, (size_t)n * sizeof(uint32_t), st));
+            hipLaunchKernelGGL(k_shade, grid_for(n), dim3(256), 0, st, sc->dev, ws.pb, ws.queue[cur], ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
+                               seed, ws.raw_queue, ws.raw_keys, ws.counts + nxt, ws.raw_squeue, ws.raw_skeys, ws.counts + 2);
+            int rc = RT_OK;
+            if (mis_shadow) rc = sort_queue(sc, n, ws.raw_skeys, ws.raw_squeue, ws.shadow_queue);
+            if (rc == RT_OK && !last_bounce) rc = sort_queue(sc, n, ws.raw_keys, ws.raw_queue, ws.queue[nxt]);
+            if (rc != RT_OK) return rc;
+        } else {
+            hipLaunchKernelGGL(k_shade, grid_for(n), dim3(256), 0, st, sc->dev, ws.pb, ws.queue[cur], ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
+                               seed, ws.queue[nxt], (uint32_t*)nullptr, ws.counts + nxt, ws.shadow_queue, (uint32_t*)nullptr, ws.counts + 2);
+        }
         tm.end();
         launches += 2;
-        if (integrator == RT_INT_MIS && sc->dev.n_lights > 0) {
+        if (mis_shadow) {
             tm.begin(CAT_TRACE);
             launch_trace(sc, count_tests, ws.shadow_queue, ws.counts + 2, n, ws.pb.shadow_rays, 0.001, 10000.0, ws.pb.shadow_prim, nullptr,
                          ws.pb.records + ((size_t)bounce * REC_FIELDS + REC_T_SHADOW) * ws.cap);  // integrator.rs:82
@@ -782,6 +847,28 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     v.mat_uses_uv = sc->d_mat_uses_uv;
     v.n_nodes = h.n_nodes; v.boxes_finite = boxes_finite ? 1u : 0u;
     v.camera = h.camera; v.n_lights = h.n_lights; v.root_node = h.root_node; v.root_end = h.root_end; v.background = h.background;
+    {   // ray-sorting grid: mean +- 2.5 sigma of the scene-level leaf-box centres (robust against a 1000-unit ground sphere
+        // or far-away light spheres); origins outside clamp to the border cells
+        double sum[3] = {0, 0, 0}, sq[3] = {0, 0, 0};
+        uint64_t cnt = 0;
+        for (uint32_t i = h.root_node; i < h.root_end; ++i) {
+            const rt_node& nd = nodes[i];
+            if ((nd.flags & RT_NODE_NO_BOX) || nd.prim0 == RT_NONE) continue;
+            bool ok = true;
+            for (int k = 0; k < 3; ++k) ok = ok && std::isfinite(nd.bmin[k]) && std::isfinite(nd.bmax[k]) && (nd.bmax[k] - nd.bmin[k]) <= 500.0;
+            if (!ok) continue;
+            for (int k = 0; k < 3; ++k) { double c = 0.5 * (nd.bmin[k] + nd.bmax[k]); sum[k] += c; sq[k] += c * c; }
+            ++cnt;
+        }
+        sc->sortable = cnt >= 64;
+        for (int k = 0; k < 3; ++k) {
+            double mean = cnt ? sum[k] / (double)cnt : 0.0;
+            double sd = cnt ? std::sqrt(std::max(sq[k] / (double)cnt - mean * mean, 0.0)) : 1.0;
+            double ext = std::max(5.0 * sd, 1e-6);
+            v.sort_min[k] = (float)(mean - 0.5 * ext);
+            v.sort_scale[k] = (float)(32.0 / ext);
+        }
+    }
     *out = sc;
     return RT_OK;
 }
@@ -909,6 +996,7 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
     Workspace& ws = sc->ws;
     hipStream_t st = sc->ctx->stream;
     const bool count_tests = (p->flags & RT_RENDER_COUNT_TESTS) != 0;
+    const bool sort_rays = (p->flags & RT_RENDER_NO_SORT) == 0 && sc->sortable;
     HIP_OK(hipMemsetAsync(ws.stats, 0, 4 * sizeof(unsigned long long), st));
     EventTimer tm(st, stats != nullptr);
     hipEvent_t e0, e1;
@@ -918,7 +1006,7 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
     for (uint32_t s0 = p->spp_begin; s0 < p->spp_end; s0 += spass) {
         const uint32_t ns = std::min(spass, p->spp_end - s0);
         const uint32_t n = npix * ns;
-        rc = run_paths(sc, n, false, p->width, p->height, s0, p->max_depth, p->integrator, p->seed, count_tests, tm, launches);
+        rc = run_paths(sc, n, false, p->width, p->height, s0, p->max_depth, p->integrator, p->seed, count_tests, sort_rays, tm, launches);
         if (rc != RT_OK) return rc;
         tm.begin(CAT_OTHER);
         hipLaunchKernelGGL(k_accumulate, grid_for(npix), dim3(256), 0, st, ws.pb.radiance, ws.cap, npix, ns, accum_dev);
@@ -1008,7 +1096,7 @@ int rt_sample_radiance(rt_scene* sc, uint32_t width, uint32_t height, uint32_t n
     HIP_OK(hipMemcpyAsync(ws.in_sample, sample_index, n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     EventTimer tm(st, false);
     uint64_t launches = 0;
-    rc = run_paths(sc, n, true, width, height, 0, max_depth, integrator, seed, false, tm, launches);
+    rc = run_paths(sc, n, true, width, height, 0, max_depth, integrator, seed, false, sc->sortable, tm, launches);
     if (rc != RT_OK) return rc;
     std::vector<double> rad(3 * (size_t)ws.cap);
     HIP_OK(hipMemcpyAsync(rad.data(), ws.pb.radiance, rad.size() * sizeof(double), hipMemcpyDeviceToHost, st));

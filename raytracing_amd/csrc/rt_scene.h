@@ -29,6 +29,7 @@ struct SceneDev {
     rt_camera camera;
     uint32_t n_lights, root_node, root_end, background;
     uint32_t n_nodes, boxes_finite;
+    float sort_min[3], sort_scale[3];  // origin quantisation grid of the ray-sorting key
 };
 
 // ---- bounding_box.rs:27-46, literal: three independent per-axis tests against the ORIGINAL
