@@ -99,19 +99,20 @@ RT_DEV bool ray_is_plain(d3 o, d3 inv) {  // box_axis_fast precondition: no NaN 
 template <int LEVEL, bool COUNT, bool INST>
 RT_DEV void test_prim(const SceneDev& sc, uint32_t p, const GeomS& g, bool pass, d3 o, d3 d, double time, double t_min, LaneHit& h, uint32_t inst_prim,
                       uint32_t& cached_xf, d3& xo, d3& xd, LaneCount& cnt) {
-    d3 ro = o, rd = d;
-    if (g.xform != RT_NONE) {  // transform.rs:25-32; one transform per (ray, distinct matrix): the pagoda wraps every triangle in the same one
-        if (g.xform != cached_xf) {
+    // (xo, xd) always hold the ray in the space of `cached_xf` (RT_NONE = the untransformed ray): transform.rs:25-32 runs once
+    // per (ray, run of primitives under the same matrix) -- the pagoda wraps every triangle in the same translation
+    if (g.xform != cached_xf) {
+        if (g.xform != RT_NONE) {
             cptr<double> m = as_const(sc.xforms[g.xform].t_inv);
             double mm[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) mm[k] = m[k];
             xo = mat_mul_xyz(mm, o, 1.0);
             xd = mat_mul_xyz(mm, d, 0.0);
-            cached_xf = g.xform;
-        }
-        ro = xo; rd = xd;
+        } else { xo = o; xd = d; }
+        cached_xf = g.xform;
     }
+    const d3 ro = xo, rd = xd;
     double t;
     if (g.kind == RT_PRIM_TRIANGLE) {
         const d3 v0 = mk(g.d[0], g.d[1], g.d[2]), e1 = mk(g.d[3], g.d[4], g.d[5]), e2 = mk(g.d[6], g.d[7], g.d[8]);
@@ -136,18 +137,16 @@ RT_DEV void test_prim(const SceneDev& sc, uint32_t p, const GeomS& g, bool pass,
 }
 
 // Wave-coherent walk of the threaded pre-order array [first, end).
-//   * `i` is the wave-uniform cursor; a lane takes part in node i iff its private `next` equals i.
-//   * A lane that fails the box of node j sets next = skip(j); because subtrees nest, any lane that is
-//     NOT active at node i has next >= skip(i).  Hence the wave goes to i+1 if any lane passed node i
+//   * `i` is the wave-uniform cursor; a lane takes part in node i iff its private `wait` is <= i.
+//   * A lane that fails the box of node j sets wait = skip(j); because subtrees nest, any lane that is
+//     NOT active at node i has wait >= skip(i).  Hence the wave goes to i+1 if any lane passed node i
 //     and to skip(i) otherwise -- no cross-lane reduction is needed.
 //   * Node i+1 is fetched (scalar load) while node i is being tested.
-template <int LEVEL, bool COUNT, bool INST>
-RT_DEV void traverse(const SceneDev& sc, uint32_t first, uint32_t end, d3 o, d3 d, double time, bool active, double t_min,
-                     LaneHit& h, uint32_t inst_prim, LaneCount& cnt) {
-    const d3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);  // bounding_box.rs:29
-    // min/max form of the slab test is exact unless a NaN can appear (zero / non-finite direction or origin): decided per wave
-    const bool plain = sc.boxes_finite && __ballot(active && !ray_is_plain(o, inv)) == 0ull && t_min == t_min;
-    uint32_t next = active ? first : 0xFFFFFFFFu;
+template <int LEVEL, bool COUNT, bool INST, bool PLAIN>
+RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, uint32_t end, d3 o, d3 d, d3 inv, double time, bool active, double t_min,
+                          LaneHit& h, uint32_t inst_prim, LaneCount& cnt) {
+    // per lane: the node index at which this ray takes part again (<= i: active now); only a failed box test moves it
+    uint32_t wait = active ? first : 0xFFFFFFFFu;
     uint32_t i = first;
     uint32_t cached_xf = RT_NONE;
     d3 xo = o, xd = d;
@@ -160,12 +159,12 @@ RT_DEV void traverse(const SceneDev& sc, uint32_t first, uint32_t end, d3 o, d3 
         const uint32_t ip1 = i + 1u;
         const NodeS nx = load_node(nodes, ip1 < last ? ip1 : last);  // speculative: the common successor
         const uint32_t p0 = nd.p0, p1 = nd.p1, skip = nd.skip, flags = nd.flags;
-        const bool act = next == i;
+        const bool act = wait <= i;
         bool pass = act;
         if (!(flags & RT_NODE_NO_BOX)) {
             if (COUNT) cnt.box += act ? 1u : 0u;
             bool bx, by, bz;
-            if (plain) {
+            if (PLAIN) {
                 bx = box_axis_fast(nd.bmin[0], nd.bmax[0], o.x, inv.x, t_min, h.best);
                 by = box_axis_fast(nd.bmin[1], nd.bmax[1], o.y, inv.y, t_min, h.best);
                 bz = box_axis_fast(nd.bmin[2], nd.bmax[2], o.z, inv.z, t_min, h.best);
@@ -176,7 +175,7 @@ RT_DEV void traverse(const SceneDev& sc, uint32_t first, uint32_t end, d3 o, d3 
             }
             pass = act & bx & by & bz;
         }
-        next = act ? (pass ? ip1 : skip) : next;
+        wait = (act & !pass) ? skip : wait;
         const bool any = __ballot(pass) != 0ull;
         if (p0 != RT_NONE && any) {
             const GeomS g0 = load_geom(geom, p0);
@@ -193,6 +192,16 @@ RT_DEV void traverse(const SceneDev& sc, uint32_t first, uint32_t end, d3 o, d3 
         if (any) { i = ip1; if (i >= end) break; nd = nx; }
         else { i = skip; if (i >= end) break; nd = load_node(nodes, i); }
     }
+}
+
+template <int LEVEL, bool COUNT, bool INST>
+RT_DEV void traverse(const SceneDev& sc, uint32_t first, uint32_t end, d3 o, d3 d, double time, bool active, double t_min,
+                     LaneHit& h, uint32_t inst_prim, LaneCount& cnt) {
+    const d3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);  // bounding_box.rs:29
+    // the min/max form of the slab test is exact unless a NaN can appear (zero / non-finite direction or origin): decided per wave
+    const bool plain = sc.boxes_finite && __ballot(active && !(ray_is_plain(o, inv) && t_min <= h.best)) == 0ull;
+    if (plain) traverse_impl<LEVEL, COUNT, INST, true>(sc, first, end, o, d, inv, time, active, t_min, h, inst_prim, cnt);
+    else traverse_impl<LEVEL, COUNT, INST, false>(sc, first, end, o, d, inv, time, active, t_min, h, inst_prim, cnt);
 }
 
 // rays: SoA [7][cap] (ox,oy,oz,dx,dy,dz,time) indexed by path; outputs indexed by path.

@@ -45,17 +45,20 @@ RT_DEV bool box_axis(double bmin, double bmax, double o, double inv, double t_mi
     return !(hi < lo);
 }
 
-// Same test with v_min/v_max (9 instead of 13 VALU ops per axis).  Bit-for-bit the same decision as
-// box_axis whenever t0 and t1 are not NaN: min/max reproduce the swap, and `a > t_min ? a : t_min`
-// == max(a, t_min) for non-NaN a (comparisons ignore the sign of zero).  t0/t1 cannot be NaN when the
-// box, the origin and 1/dir are finite and 1/dir != 0 -- the kernel checks that per wave and
-// falls back to box_axis otherwise.
+// Fast form, 8 VALU ops per axis.  With a = min(t0,t1), b = max(t0,t1):
+//   literal: lo = max(a, t_min), hi = min(b, t_max), pass iff !(hi < lo)
+//        <=> a <= t_max  &&  b >= t_min            (given t_min <= t_max and a <= b)
+// Bit-for-bit the same decision as box_axis whenever t0, t1 are not NaN (min/max reproduce the swap;
+// comparisons ignore the sign of zero).  t0/t1 cannot be NaN when the box, the origin and 1/dir are
+// finite and 1/dir != 0; t_max (the running best) never drops below t_min because every primitive
+// test rejects t < t_min.  The kernel checks these preconditions per wave and otherwise uses box_axis.
+// v_min_f64 / v_max_f64 are issued directly: fmin()/fmax() would add a canonicalising v_max x,x each.
+RT_DEV double vmin_f64(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+RT_DEV double vmax_f64(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 RT_DEV bool box_axis_fast(double bmin, double bmax, double o, double inv, double t_min, double t_max) {
     double t0 = (bmin - o) * inv;
     double t1 = (bmax - o) * inv;
-    double lo = fmax(fmin(t0, t1), t_min);
-    double hi = fmin(fmax(t0, t1), t_max);
-    return !(hi < lo);
+    return (vmin_f64(t0, t1) <= t_max) & (vmax_f64(t0, t1) >= t_min);
 }
 
 // ---- primitive tests: return true and t when the reference's `hit` returns Some --------------
@@ -78,11 +81,13 @@ RT_DEV bool tri_hit(d3 v0, d3 edge1, d3 edge2, d3 o, d3 d, double t_min, double 
     return true;
 }
 // Wave-friendly staging of the same test.  Stage A computes the reference's own h, det, s and s.h
-// (same operations, same order) and applies a CONSERVATIVE rejection that is implied by the
-// reference's `u` test, so the 1/det division and the rest run only for lanes that may still hit:
-//   |det| in [EPS, 1e280]  =>  det_inv = RN(1/det) is normal with relative error <= 2^-53, and
-//   (R1) s.h and det of opposite sign with |s.h| >= 1e-20  =>  u = RN(det_inv * s.h) is a negative
-//        normal number  =>  `u >= 0` fails;
+// (same operations, same order) and applies a CONSERVATIVE rejection implied by the reference's
+// tests, so the 1/det division and the rest run only for lanes that may still hit:
+//   (E)  !(|det| >= EPS): the reference returns None at mesh.rs:59-61, or det is NaN and its `u` test fails;
+//   for EPS <= |det| <= 1e100, det_inv = RN(1/det) is a normal number with relative error <= 2^-53, and
+//   (R1) RN(s.h * det) < -1e-36  =>  s.h and det have opposite signs and |s.h / det| > 1e-36 / det^2 >= 1e-236, so
+//        u = RN(det_inv * s.h) is a negative NORMAL number and `u >= 0` fails (a negative u that
+//        underflowed to -0 would pass `u >= 0`, hence the magnitude floor);
 //   (R2) |s.h| > RN(|det| * (1 + 2^-40))  =>  |det_inv * s.h| > (1 + 2^-41)(1 - 2^-53) > 1  =>  u < 0 or u > 1.
 // Everything not rejected here is decided by the literal code of tri_hit_tail.
 struct TriStage { d3 h, s; double det, sh; };
@@ -91,12 +96,12 @@ RT_DEV bool tri_stage_a(d3 v0, d3 edge1, d3 edge2, d3 o, d3 d, TriStage& st) {
     st.det = dot(edge1, st.h);
     st.s = o - v0;
     st.sh = dot(st.s, st.h);
-    const double ad = fabs(st.det), as = fabs(st.sh);
-    if (st.det > -F64_EPS && st.det < F64_EPS) return false;                       // mesh.rs:59-61
-    const bool in_range = ad <= 1e280;
-    const bool r2 = as > ad * 1.0000000000009094947;                               // 1 + 2^-40
-    const bool r1 = ((st.sh < 0.0) != (st.det < 0.0)) && as >= 1e-20;
-    return !(in_range && (r1 || r2));
+    const double ad = fabs(st.det);
+    const bool e_ok = ad >= F64_EPS;
+    const bool in_range = ad <= 1e100;
+    const bool r1 = st.sh * st.det < -1e-36;
+    const bool r2 = fabs(st.sh) > ad * 1.0000000000009094947;  // 1 + 2^-40
+    return e_ok & !(in_range & (r1 | r2));
 }
 RT_DEV bool tri_hit_tail(const TriStage& st, d3 edge1, d3 edge2, d3 d, double t_min, double t_max, double& t_out) {
     double det_inv = 1.0 / st.det;
