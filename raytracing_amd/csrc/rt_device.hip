@@ -69,168 +69,251 @@ struct LaneHit {
 };
 struct LaneCount { uint32_t box, tri, sph; };
 
-struct NodeS { double bmin[3], bmax[3]; uint32_t skip, flags, p0, p1; };  // one s_load_dwordx16
-RT_DEV NodeS load_node(cptr<rt_node> nodes, uint32_t i) {
-    const RT_CONST rt_node& n = nodes[i];
-    NodeS r;
-    r.bmin[0] = n.bmin[0]; r.bmin[1] = n.bmin[1]; r.bmin[2] = n.bmin[2];
-    r.bmax[0] = n.bmax[0]; r.bmax[1] = n.bmax[1]; r.bmax[2] = n.bmax[2];
-    r.skip = n.skip; r.flags = n.flags; r.p0 = n.prim0; r.p1 = n.prim1;
-    return r;
+struct GeomS { double d[9]; uint32_t kind, xform; };
+
+// ---- the trace stream ---------------------------------------------------------------------------
+// rt_scene_upload re-packs the blob's node / geom tables into one pre-order byte stream of records
+//     [64 B header: box (6 f64) | skip_off | flags + (nprims << 8) | prim0 | prim1] [80 B rt_geom] x nprims
+// so that everything a traversal step needs sits in ONE contiguous window.  Each step issues the
+// whole window (header + both geometry slots + the line after them) as back-to-back scalar loads and
+// waits once: a step costs one scalar-cache latency instead of up to three dependent ones (node ->
+// geom 0 -> geom 1), and the trailing bytes are the records the walk visits next when it continues
+// sequentially, so those steps hit the scalar cache.  The loads are inline asm because the compiler
+// sinks ordinary loads to their first use, which re-serialises them.
+#define RT_STREAM_HDR 64u
+#define RT_STREAM_GEOM 80u
+#define RT_STREAM_PAD 384u  /* readable bytes past the last record: the window over-reads */
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+struct Window { u32x16 h, a, b; u32x8 c; uint32_t p; };
+RT_DEV void window_issue(Window& w, uint64_t addr) {
+    asm volatile("s_load_dwordx16 %0, %5, 0x0\n\t"
+                 "s_load_dwordx16 %1, %5, 0x40\n\t"
+                 "s_load_dwordx16 %2, %5, 0x80\n\t"
+                 "s_load_dwordx8 %3, %5, 0xc0\n\t"
+                 "s_load_dword %4, %5, 0x100"
+                 : "=&s"(w.h), "=&s"(w.a), "=&s"(w.b), "=&s"(w.c), "=&s"(w.p) : "s"(addr));
 }
-struct GeomS { double d[9]; uint32_t kind, xform; };  // 80 B: s_load_dwordx16 + x4
-RT_DEV GeomS load_geom(cptr<rt_geom> geom, uint32_t p) {
-    const RT_CONST rt_geom& g = geom[p];
-    GeomS r;
+// `touch` is the destination of an earlier fire-and-forget load: it must stay allocated until that load has landed
+RT_DEV void window_wait(Window& w, uint32_t& touch) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w.h), "+s"(w.a), "+s"(w.b), "+s"(w.c), "+s"(w.p), "+s"(touch));
+}
+RT_DEV void stream_touch(uint32_t& touch, uint64_t addr) { asm volatile("s_load_dword %0, %1, 0x0" : "=&s"(touch) : "s"(addr)); }
+RT_DEV double sdbl(uint32_t lo, uint32_t hi) { return __builtin_bit_cast(double, ((uint64_t)hi << 32) | (uint64_t)lo); }
+RT_DEV GeomS window_geom0(const Window& w) {  // stream bytes [64, 144)
+    GeomS g;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) r.d[k] = g.d[k];
-    r.kind = g.kind; r.xform = g.xform;
-    return r;
+    for (int k = 0; k < 8; ++k) g.d[k] = sdbl(w.a[2 * k], w.a[2 * k + 1]);
+    g.d[8] = sdbl(w.b[0], w.b[1]); g.kind = w.b[2]; g.xform = w.b[3];
+    return g;
+}
+RT_DEV GeomS window_geom1(const Window& w) {  // stream bytes [144, 224)
+    GeomS g;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) g.d[k] = sdbl(w.b[4 + 2 * k], w.b[5 + 2 * k]);
+    g.d[6] = sdbl(w.c[0], w.c[1]); g.d[7] = sdbl(w.c[2], w.c[3]); g.d[8] = sdbl(w.c[4], w.c[5]); g.kind = w.c[6]; g.xform = w.c[7];
+    return g;
 }
 
-template <int LEVEL, bool COUNT, bool INST>
-RT_DEV void traverse(const SceneDev& sc, uint32_t first, uint32_t end, d3 o, d3 d, double time, bool active, double t_min,
-                     LaneHit& h, uint32_t inst_prim, LaneCount& cnt);
+// Each lane carries R rays (R = RT_RAYS_PER_LANE): a wave walks the node array once for 64*R rays, so the
+// wave-uniform work per node (scalar loads, cursor, branches -- all issued on the CU's single scalar
+// unit) is amortised over R box tests per lane, and the R independent tests give the VALU ILP.
+#define RT_RAYS_PER_LANE 1
+template <int R> struct Rays {
+    d3 o[R], d[R];       // ray as handed to this traversal level
+    d3 xo[R], xd[R];     // ray in the space of the cached transform (RT_NONE: == o, d)
+    double time[R];
+    LaneHit h[R];
+};
+
+template <int LEVEL, bool COUNT, bool INST, int R>
+RT_DEV void traverse(const SceneDev& sc, uint32_t first, uint32_t end, Rays<R>& ry, const bool (&active)[R], double t_min, uint32_t inst_prim, LaneCount& cnt);
 
 RT_DEV bool ray_is_plain(d3 o, d3 inv) {  // box_axis_fast precondition: no NaN can appear in (b - o) * inv
     return isfinite(o.x) && isfinite(o.y) && isfinite(o.z) && isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z) && inv.x != 0.0 && inv.y != 0.0 && inv.z != 0.0;
 }
 
-template <int LEVEL, bool COUNT, bool INST>
-RT_DEV void test_prim(const SceneDev& sc, uint32_t p, const GeomS& g, bool pass, d3 o, d3 d, double time, double t_min, LaneHit& h, uint32_t inst_prim,
-                      uint32_t& cached_xf, d3& xo, d3& xd, LaneCount& cnt) {
-    // (xo, xd) always hold the ray in the space of `cached_xf` (RT_NONE = the untransformed ray): transform.rs:25-32 runs once
-    // per (ray, run of primitives under the same matrix) -- the pagoda wraps every triangle in the same translation
+template <int LEVEL, bool COUNT, bool INST, int R>
+RT_DEV void test_prim(const SceneDev& sc, uint32_t p, const GeomS& g, const bool (&pass)[R], Rays<R>& ry, double t_min, uint32_t inst_prim,
+                      uint32_t& cached_xf, LaneCount& cnt) {
+    // (xo, xd) always hold the rays in the space of `cached_xf` (RT_NONE = untransformed): transform.rs:25-32 runs once per
+    // (ray, run of primitives under the same matrix) -- the pagoda wraps every triangle in the same translation
     if (g.xform != cached_xf) {
         if (g.xform != RT_NONE) {
             cptr<double> m = as_const(sc.xforms[g.xform].t_inv);
             double mm[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) mm[k] = m[k];
-            xo = mat_mul_xyz(mm, o, 1.0);
-            xd = mat_mul_xyz(mm, d, 0.0);
-        } else { xo = o; xd = d; }
+#pragma unroll
+            for (int r = 0; r < R; ++r) { ry.xo[r] = mat_mul_xyz(mm, ry.o[r], 1.0); ry.xd[r] = mat_mul_xyz(mm, ry.d[r], 0.0); }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) { ry.xo[r] = ry.o[r]; ry.xd[r] = ry.d[r]; }
+        }
         cached_xf = g.xform;
     }
-    const d3 ro = xo, rd = xd;
-    double t;
     if (g.kind == RT_PRIM_TRIANGLE) {
         const d3 v0 = mk(g.d[0], g.d[1], g.d[2]), e1 = mk(g.d[3], g.d[4], g.d[5]), e2 = mk(g.d[6], g.d[7], g.d[8]);
-        if (COUNT) cnt.tri += pass ? 1u : 0u;
-        TriStage st;
-        const bool alive = tri_stage_a(v0, e1, e2, ro, rd, st) & pass;
-        if (__ballot(alive) != 0ull) {  // rare: most tested triangles are nowhere near the ray
-            if (alive && tri_hit_tail(st, e1, e2, rd, t_min, h.best, t)) { h.best = t; h.prim = p; h.inst = inst_prim; }
+        TriStage st[R];
+        bool alive[R], any_alive = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (COUNT) cnt.tri += pass[r] ? 1u : 0u;
+            alive[r] = tri_stage_a(v0, e1, e2, ry.xo[r], ry.xd[r], st[r]) & pass[r];
+            any_alive |= alive[r];
         }
-    } else if (g.kind == RT_PRIM_SPHERE) {
-        if (COUNT) cnt.sph += pass ? 1u : 0u;
-        if (pass && sphere_hit(mk(g.d[0], g.d[1], g.d[2]), g.d[3], ro, rd, t_min, h.best, t)) { h.best = t; h.prim = p; h.inst = inst_prim; }
-    } else if (g.kind == RT_PRIM_MOVING_SPHERE) {
-        if (COUNT) cnt.sph += pass ? 1u : 0u;
-        d3 c = moving_center(mk(g.d[0], g.d[1], g.d[2]), mk(g.d[3], g.d[4], g.d[5]), g.d[6], g.d[7], time);
-        if (pass && sphere_hit(c, g.d[8], ro, rd, t_min, h.best, t)) { h.best = t; h.prim = p; h.inst = inst_prim; }
+        if (__ballot(any_alive) != 0ull) {  // rare: most tested triangles are nowhere near the rays
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                double t;
+                if (alive[r] && tri_hit_tail(st[r], e1, e2, ry.xd[r], t_min, ry.h[r].best, t)) { ry.h[r].best = t; ry.h[r].prim = p; ry.h[r].inst = inst_prim; }
+            }
+        }
+    } else if (g.kind == RT_PRIM_SPHERE || g.kind == RT_PRIM_MOVING_SPHERE) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (COUNT) cnt.sph += pass[r] ? 1u : 0u;
+            d3 c = mk(g.d[0], g.d[1], g.d[2]);
+            double radius = g.d[3], t;
+            if (g.kind == RT_PRIM_MOVING_SPHERE) { c = moving_center(c, mk(g.d[3], g.d[4], g.d[5]), g.d[6], g.d[7], ry.time[r]); radius = g.d[8]; }
+            if (pass[r] && sphere_hit(c, radius, ry.xo[r], ry.xd[r], t_min, ry.h[r].best, t)) { ry.h[r].best = t; ry.h[r].prim = p; ry.h[r].inst = inst_prim; }
+        }
     } else if (g.kind == RT_PRIM_AARECT) {
-        if (pass && rect_hit(g.d[0], g.d[1], g.d[2], g.d[3], g.d[4], ro, rd, t_min, h.best, t)) { h.best = t; h.prim = p; h.inst = inst_prim; }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            double t;
+            if (pass[r] && rect_hit(g.d[0], g.d[1], g.d[2], g.d[3], g.d[4], ry.xo[r], ry.xd[r], t_min, ry.h[r].best, t)) { ry.h[r].best = t; ry.h[r].prim = p; ry.h[r].inst = inst_prim; }
+        }
     } else if constexpr (LEVEL == 0 && INST) {  // RT_PRIM_INSTANCE: BVHNode object (optionally under a Transformed), main.rs:161-188
-        traverse<1, COUNT, INST>(sc, (uint32_t)g.d[0], (uint32_t)g.d[1], ro, rd, time, pass, t_min, h, p, cnt);
+        Rays<R> sub;
+#pragma unroll
+        for (int r = 0; r < R; ++r) { sub.o[r] = ry.xo[r]; sub.d[r] = ry.xd[r]; sub.xo[r] = ry.xo[r]; sub.xd[r] = ry.xd[r]; sub.time[r] = ry.time[r]; sub.h[r] = ry.h[r]; }
+        traverse<1, COUNT, INST, R>(sc, (uint32_t)g.d[0], (uint32_t)g.d[1], sub, pass, t_min, p, cnt);
+#pragma unroll
+        for (int r = 0; r < R; ++r) ry.h[r] = sub.h[r];
     }
 }
 
-// Wave-coherent walk of the threaded pre-order array [first, end).
-//   * `i` is the wave-uniform cursor; a lane takes part in node i iff its private `wait` is <= i.
-//   * A lane that fails the box of node j sets wait = skip(j); because subtrees nest, any lane that is
-//     NOT active at node i has wait >= skip(i).  Hence the wave goes to i+1 if any lane passed node i
-//     and to skip(i) otherwise -- no cross-lane reduction is needed.
-//   * Node i+1 is fetched (scalar load) while node i is being tested.
-template <int LEVEL, bool COUNT, bool INST, bool PLAIN>
-RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, uint32_t end, d3 o, d3 d, d3 inv, double time, bool active, double t_min,
-                          LaneHit& h, uint32_t inst_prim, LaneCount& cnt) {
-    // per lane: the node index at which this ray takes part again (<= i: active now); only a failed box test moves it
-    uint32_t wait = active ? first : 0xFFFFFFFFu;
-    uint32_t i = first;
+// Wave-coherent walk of the stream records in byte range [first, end).
+//   * `off` is the wave-uniform cursor; ray r of a lane takes part in a record iff its private wait[r] is <= off.
+//   * A ray that fails the box of record j sets wait = skip(j); because subtrees nest, any ray that is
+//     NOT active at record i has wait >= skip(i).  Hence the wave goes to the next record if any ray
+//     passed and to skip(i) otherwise -- no cross-lane reduction is needed.
+template <int LEVEL, bool COUNT, bool INST, bool PLAIN, int R>
+RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, uint32_t end, Rays<R>& ry, const d3 (&inv)[R], const bool (&active)[R], double t_min,
+                          uint32_t inst_prim, LaneCount& cnt) {
+    uint32_t wait[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { wait[r] = active[r] ? first : 0xFFFFFFFFu; ry.xo[r] = ry.o[r]; ry.xd[r] = ry.d[r]; }
+    uint32_t off = first, touch = 0u;
     uint32_t cached_xf = RT_NONE;
-    d3 xo = o, xd = d;
-    cptr<rt_node> nodes = as_const(sc.nodes);
-    cptr<rt_geom> geom = as_const(sc.geom);
-    if (i >= end) return;
-    const uint32_t last = sc.n_nodes - 1u;
-    NodeS nd = load_node(nodes, i);
-    for (;;) {
-        const uint32_t ip1 = i + 1u;
-        const NodeS nx = load_node(nodes, ip1 < last ? ip1 : last);  // speculative: the common successor
-        const uint32_t p0 = nd.p0, p1 = nd.p1, skip = nd.skip, flags = nd.flags;
-        const bool act = wait <= i;
-        bool pass = act;
-        if (!(flags & RT_NODE_NO_BOX)) {
-            if (COUNT) cnt.box += act ? 1u : 0u;
-            bool bx, by, bz;
-            if (PLAIN) {
-                bx = box_axis_fast(nd.bmin[0], nd.bmax[0], o.x, inv.x, t_min, h.best);
-                by = box_axis_fast(nd.bmin[1], nd.bmax[1], o.y, inv.y, t_min, h.best);
-                bz = box_axis_fast(nd.bmin[2], nd.bmax[2], o.z, inv.z, t_min, h.best);
-            } else {
-                bx = box_axis(nd.bmin[0], nd.bmax[0], o.x, inv.x, t_min, h.best);
-                by = box_axis(nd.bmin[1], nd.bmax[1], o.y, inv.y, t_min, h.best);
-                bz = box_axis(nd.bmin[2], nd.bmax[2], o.z, inv.z, t_min, h.best);
+    const uint64_t base = (uint64_t)sc.stream;
+    while (off < end) {
+        Window w;
+        window_issue(w, base + off);
+        window_wait(w, touch);
+        const uint32_t skip = w.h[12], flags = w.h[13], p0 = w.h[14], p1 = w.h[15];
+        const uint32_t nprims = flags >> 8;
+        const uint32_t next = off + RT_STREAM_HDR + RT_STREAM_GEOM * nprims;
+        if (nprims == 0u) stream_touch(touch, base + skip);  // inner node: warm the skip target while the box tests run
+        const double bmin[3] = {sdbl(w.h[0], w.h[1]), sdbl(w.h[2], w.h[3]), sdbl(w.h[4], w.h[5])};
+        const double bmax[3] = {sdbl(w.h[6], w.h[7]), sdbl(w.h[8], w.h[9]), sdbl(w.h[10], w.h[11])};
+        bool pass[R], any_pass = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool act = wait[r] <= off;
+            pass[r] = act;
+            if (!(flags & RT_NODE_NO_BOX)) {
+                if (COUNT) cnt.box += act ? 1u : 0u;
+                bool bx, by, bz;
+                if (PLAIN) {
+                    bx = box_axis_fast(bmin[0], bmax[0], ry.o[r].x, inv[r].x, t_min, ry.h[r].best);
+                    by = box_axis_fast(bmin[1], bmax[1], ry.o[r].y, inv[r].y, t_min, ry.h[r].best);
+                    bz = box_axis_fast(bmin[2], bmax[2], ry.o[r].z, inv[r].z, t_min, ry.h[r].best);
+                } else {
+                    bx = box_axis(bmin[0], bmax[0], ry.o[r].x, inv[r].x, t_min, ry.h[r].best);
+                    by = box_axis(bmin[1], bmax[1], ry.o[r].y, inv[r].y, t_min, ry.h[r].best);
+                    bz = box_axis(bmin[2], bmax[2], ry.o[r].z, inv[r].z, t_min, ry.h[r].best);
+                }
+                pass[r] = act & bx & by & bz;
             }
-            pass = act & bx & by & bz;
+            wait[r] = (act & !pass[r]) ? skip : wait[r];
+            any_pass |= pass[r];
         }
-        wait = (act & !pass) ? skip : wait;
-        const bool any = __ballot(pass) != 0ull;
-        if (p0 != RT_NONE && any) {
-            const GeomS g0 = load_geom(geom, p0);
-            test_prim<LEVEL, COUNT, INST>(sc, p0, g0, pass, o, d, time, t_min, h, inst_prim, cached_xf, xo, xd, cnt);
-            if (p1 != RT_NONE) {
-                const GeomS g1 = load_geom(geom, p1);
-                test_prim<LEVEL, COUNT, INST>(sc, p1, g1, pass, o, d, time, t_min, h, inst_prim, cached_xf, xo, xd, cnt);
+        const bool any = __ballot(any_pass) != 0ull;
+        if (nprims != 0u && any) {
+            const GeomS g0 = window_geom0(w);
+            test_prim<LEVEL, COUNT, INST, R>(sc, p0, g0, pass, ry, t_min, inst_prim, cached_xf, cnt);
+            if (nprims > 1u) {
+                const GeomS g1 = window_geom1(w);
+                test_prim<LEVEL, COUNT, INST, R>(sc, p1, g1, pass, ry, t_min, inst_prim, cached_xf, cnt);
             }
             if (COUNT && (flags & RT_NODE_DUP_RIGHT)) {  // reference-order count of the skipped duplicate test
-                if (g0.kind == RT_PRIM_TRIANGLE) cnt.tri += pass ? 1u : 0u;
-                else if (g0.kind == RT_PRIM_SPHERE || g0.kind == RT_PRIM_MOVING_SPHERE) cnt.sph += pass ? 1u : 0u;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (g0.kind == RT_PRIM_TRIANGLE) cnt.tri += pass[r] ? 1u : 0u;
+                    else if (g0.kind == RT_PRIM_SPHERE || g0.kind == RT_PRIM_MOVING_SPHERE) cnt.sph += pass[r] ? 1u : 0u;
+                }
             }
         }
-        if (any) { i = ip1; if (i >= end) break; nd = nx; }
-        else { i = skip; if (i >= end) break; nd = load_node(nodes, i); }
+        off = any ? next : skip;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(touch));  // the last touch load must land before its register is reused
 }
 
-template <int LEVEL, bool COUNT, bool INST>
-RT_DEV void traverse(const SceneDev& sc, uint32_t first, uint32_t end, d3 o, d3 d, double time, bool active, double t_min,
-                     LaneHit& h, uint32_t inst_prim, LaneCount& cnt) {
-    const d3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);  // bounding_box.rs:29
+template <int LEVEL, bool COUNT, bool INST, int R>
+RT_DEV void traverse(const SceneDev& sc, uint32_t first, uint32_t end, Rays<R>& ry, const bool (&active)[R], double t_min, uint32_t inst_prim, LaneCount& cnt) {
+    d3 inv[R];
+    bool odd = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        inv[r] = mk(1.0 / ry.d[r].x, 1.0 / ry.d[r].y, 1.0 / ry.d[r].z);  // bounding_box.rs:29
+        odd |= active[r] && !(ray_is_plain(ry.o[r], inv[r]) && t_min <= ry.h[r].best);
+    }
     // the min/max form of the slab test is exact unless a NaN can appear (zero / non-finite direction or origin): decided per wave
-    const bool plain = sc.boxes_finite && __ballot(active && !(ray_is_plain(o, inv) && t_min <= h.best)) == 0ull;
-    if (plain) traverse_impl<LEVEL, COUNT, INST, true>(sc, first, end, o, d, inv, time, active, t_min, h, inst_prim, cnt);
-    else traverse_impl<LEVEL, COUNT, INST, false>(sc, first, end, o, d, inv, time, active, t_min, h, inst_prim, cnt);
+    const bool plain = sc.boxes_finite && __ballot(odd) == 0ull;
+    if (plain) traverse_impl<LEVEL, COUNT, INST, true, R>(sc, first, end, ry, inv, active, t_min, inst_prim, cnt);
+    else traverse_impl<LEVEL, COUNT, INST, false, R>(sc, first, end, ry, inv, active, t_min, inst_prim, cnt);
 }
 
 // rays: SoA [7][cap] (ox,oy,oz,dx,dy,dz,time) indexed by path; outputs indexed by path.
+// A wave owns 64*R consecutive queue entries; lane l takes entries l, l+64, ... of that block.
 template <bool COUNT, bool INST>
 __global__ __launch_bounds__(256) void k_trace(SceneDev sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_fixed,
                                                const double* __restrict__ rays, uint32_t cap, double t_min, double t_max,
                                                uint32_t* __restrict__ out_prim, uint32_t* __restrict__ out_inst, double* __restrict__ out_t,
                                                unsigned long long* __restrict__ stats) {
+    constexpr int R = RT_RAYS_PER_LANE;
     const uint32_t n = n_ptr ? *n_ptr : n_fixed;
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t wave_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(gid & ~63u));
-    if (gid == 0 && stats) atomicAdd(&stats[0], (unsigned long long)n);  // rays traced
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t wave_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)((tid & ~63u) * R));
+    if (tid == 0 && stats) atomicAdd(&stats[0], (unsigned long long)n);  // rays traced
     if (wave_first >= n) return;
-    const bool valid = gid < n;
-    const uint32_t path = valid ? (queue ? queue[gid] : gid) : 0u;
-    d3 o = mk(0, 0, 0), d = mk(1, 1, 1);
-    double time = 0.0;
-    if (valid) {
-        o = mk(rays[0 * (size_t)cap + path], rays[1 * (size_t)cap + path], rays[2 * (size_t)cap + path]);
-        d = mk(rays[3 * (size_t)cap + path], rays[4 * (size_t)cap + path], rays[5 * (size_t)cap + path]);
-        time = rays[6 * (size_t)cap + path];
+    Rays<R> ry;
+    bool valid[R];
+    uint32_t path[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t q = wave_first + (tid & 63u) + 64u * r;
+        valid[r] = q < n;
+        path[r] = valid[r] ? (queue ? queue[q] : q) : 0u;
+        ry.o[r] = mk(0, 0, 0); ry.d[r] = mk(1, 1, 1); ry.time[r] = 0.0;
+        if (valid[r]) {
+            ry.o[r] = mk(rays[0 * (size_t)cap + path[r]], rays[1 * (size_t)cap + path[r]], rays[2 * (size_t)cap + path[r]]);
+            ry.d[r] = mk(rays[3 * (size_t)cap + path[r]], rays[4 * (size_t)cap + path[r]], rays[5 * (size_t)cap + path[r]]);
+            ry.time[r] = rays[6 * (size_t)cap + path[r]];
+        }
+        ry.h[r].best = t_max; ry.h[r].prim = RT_NONE; ry.h[r].inst = RT_NONE;
     }
-    LaneHit h; h.best = t_max; h.prim = RT_NONE; h.inst = RT_NONE;
     LaneCount cnt; cnt.box = cnt.tri = cnt.sph = 0;
-    traverse<0, COUNT, INST>(sc, sc.root_node, sc.root_end, o, d, time, valid, t_min, h, RT_NONE, cnt);
-    if (valid) {
-        out_prim[path] = h.prim;
-        if (out_inst) out_inst[path] = h.inst;
-        out_t[path] = h.prim != RT_NONE ? h.best : __builtin_nan("");
+    traverse<0, COUNT, INST, R>(sc, sc.root_off, sc.root_end_off, ry, valid, t_min, RT_NONE, cnt);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (valid[r]) {
+            out_prim[path[r]] = ry.h[r].prim;
+            if (out_inst) out_inst[path[r]] = ry.h[r].inst;
+            out_t[path[r]] = ry.h[r].prim != RT_NONE ? ry.h[r].best : __builtin_nan("");
+        }
     }
     if (COUNT && stats) {
         uint64_t b = wave_sum_u64(cnt.box), t = wave_sum_u64(cnt.tri), s = wave_sum_u64(cnt.sph);
@@ -553,6 +636,7 @@ struct rt_scene {
     rt_context* ctx;
     void* dblob = nullptr;
     uint8_t* d_mat_uses_uv = nullptr;
+    uint8_t* d_stream = nullptr;
     SceneDev dev{};
     rt_blob_header hdr{};
     std::vector<rt_prim> host_prims;
@@ -632,7 +716,7 @@ static void launch_trace(rt_scene* sc, bool count, const uint32_t* queue, const 
                          double t_max, uint32_t* out_prim, uint32_t* out_inst, double* out_t) {
     hipStream_t st = sc->ctx->stream;
     if (n_bound == 0) return;
-#define RT_LAUNCH_TRACE(C, I) hipLaunchKernelGGL((k_trace<C, I>), grid_for(n_bound), dim3(256), 0, st, sc->dev, queue, n_ptr, n_bound, rays, sc->ws.cap, t_min, t_max, out_prim, out_inst, out_t, sc->ws.stats)
+#define RT_LAUNCH_TRACE(C, I) hipLaunchKernelGGL((k_trace<C, I>), grid_for((n_bound + RT_RAYS_PER_LANE - 1) / RT_RAYS_PER_LANE), dim3(256), 0, st, sc->dev, queue, n_ptr, n_bound, rays, sc->ws.cap, t_min, t_max, out_prim, out_inst, out_t, sc->ws.stats)
     const bool inst = sc->has_instances;  // scenes without BVHNode objects use the kernel variant compiled without the nested walk
     if (count) { if (inst) RT_LAUNCH_TRACE(true, true); else RT_LAUNCH_TRACE(true, false); }
     else { if (inst) RT_LAUNCH_TRACE(false, true); else RT_LAUNCH_TRACE(false, false); }
@@ -836,13 +920,39 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     sc->ctx = ctx; sc->hdr = h;
     sc->host_prims.assign(prims, prims + h.n_prims);
     for (uint32_t i = 0; i < h.n_prims; ++i) sc->has_instances = sc->has_instances || prims[i].kind == RT_PRIM_INSTANCE;
+    // trace stream: pre-order records, header + inline leaf geometry (see k_trace)
+    std::vector<uint64_t> rec_off((size_t)h.n_nodes + 1);
+    uint64_t stream_bytes = 0;
+    for (uint32_t i = 0; i < h.n_nodes; ++i) {
+        rec_off[i] = stream_bytes;
+        stream_bytes += RT_STREAM_HDR + RT_STREAM_GEOM * ((nodes[i].prim0 != RT_NONE) + (nodes[i].prim1 != RT_NONE));
+    }
+    rec_off[h.n_nodes] = stream_bytes;
+    if (stream_bytes + RT_STREAM_PAD > 0xFFFFFFF0ull) { delete sc; return fail(RT_ERR_UNSUPPORTED, "trace stream larger than 4 GiB"); }
+    std::vector<uint8_t> stream((size_t)stream_bytes + RT_STREAM_PAD, 0);
+    for (uint32_t i = 0; i < h.n_nodes; ++i) {
+        uint8_t* rec = stream.data() + rec_off[i];
+        const uint32_t np = (nodes[i].prim0 != RT_NONE) + (nodes[i].prim1 != RT_NONE);
+        const uint32_t words[4] = {(uint32_t)rec_off[nodes[i].skip], (nodes[i].flags & 0xFFu) | (np << 8), nodes[i].prim0, nodes[i].prim1};
+        memcpy(rec, nodes[i].bmin, 24); memcpy(rec + 24, nodes[i].bmax, 24); memcpy(rec + 48, words, 16);
+        uint32_t slot = 0;
+        for (uint32_t q : {nodes[i].prim0, nodes[i].prim1}) {
+            if (q == RT_NONE) continue;
+            rt_geom g = geom[q];
+            if (g.kind == RT_PRIM_INSTANCE) { g.d[0] = (double)rec_off[prims[q].index]; g.d[1] = (double)rec_off[prims[q].sub_end]; }
+            memcpy(rec + RT_STREAM_HDR + RT_STREAM_GEOM * slot++, &g, sizeof g);
+        }
+    }
     hipError_t e = hipMalloc(&sc->dblob, nbytes);
     if (e == hipSuccess) e = hipMalloc((void**)&sc->d_mat_uses_uv, uses_uv.size());
+    if (e == hipSuccess) e = hipMalloc((void**)&sc->d_stream, stream.size());
+    if (e == hipSuccess) e = hipMemcpy(sc->d_stream, stream.data(), stream.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(sc->dblob, blob, nbytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(sc->d_mat_uses_uv, uses_uv.data(), uses_uv.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         if (sc->dblob) (void)hipFree(sc->dblob);
         if (sc->d_mat_uses_uv) (void)hipFree(sc->d_mat_uses_uv);
+        if (sc->d_stream) (void)hipFree(sc->d_stream);
         delete sc;
         return fail(e == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, hipGetErrorString(e));
     }
@@ -854,6 +964,7 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     v.materials = (const rt_material*)(d + h.off_materials); v.textures = (const rt_texture*)(d + h.off_textures);
     v.texels = d + h.off_texels; v.lights = (const rt_light*)(d + h.off_lights);
     v.mat_uses_uv = sc->d_mat_uses_uv;
+    v.stream = sc->d_stream; v.root_off = (uint32_t)rec_off[h.root_node]; v.root_end_off = (uint32_t)rec_off[h.root_end];
     v.n_nodes = h.n_nodes; v.boxes_finite = boxes_finite ? 1u : 0u;
     v.camera = h.camera; v.n_lights = h.n_lights; v.root_node = h.root_node; v.root_end = h.root_end; v.background = h.background;
     {   // ray-sorting grid: mean +- 2.5 sigma of the scene-level leaf-box centres (robust against a 1000-unit ground sphere
@@ -889,6 +1000,7 @@ int rt_scene_destroy(rt_scene* sc) {
     ws_free(sc->ws);
     (void)hipFree(sc->dblob);
     (void)hipFree(sc->d_mat_uses_uv);
+    (void)hipFree(sc->d_stream);
     delete sc;
     return RT_OK;
 }

@@ -26,6 +26,8 @@ struct SceneDev {
     const uint8_t* texels;
     const rt_light* lights;
     const uint8_t* mat_uses_uv;
+    const uint8_t* stream;  // trace stream (rt_device.hip): node headers with their leaf geometry inline
+    uint32_t root_off, root_end_off;  // byte range of the scene-level records in `stream`
     rt_camera camera;
     uint32_t n_lights, root_node, root_end, background;
     uint32_t n_nodes, boxes_finite;
