@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HOST_LIB = os.path.join(_HERE, "host", "librt_host.so")
-HIP_LIB = os.path.join(_HERE, "csrc", "librt_hip.so")
+HIP_LIB = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "csrc", "librt_hip.so")  # RT_HIP_LIB: diagnostic builds only
 ASSETS = os.path.join(os.path.dirname(_HERE), "assets")
 
 u32, u64, i32, f64, f32 = C.c_uint32, C.c_uint64, C.c_int32, C.c_double, C.c_float

@@ -23,6 +23,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <limits>
 #include <vector>
 
 using namespace rt;
@@ -67,38 +68,49 @@ struct LaneHit {
     double best;         // current t_max (bvh.rs:98-101)
     uint32_t prim, inst; // indices into the prims table
 };
-struct LaneCount { uint32_t box, tri, sph; };
+struct LaneCount {
+    uint32_t box, tri, sph;
+#ifdef RT_TRACE_DIAG  // diagnostic build only (make diag): wave-level step counts and s_memtime cycle stamps
+    uint64_t steps, leaf_steps, cyc_wait, cyc_total;
+#endif
+};
 
 struct GeomS { double d[9]; uint32_t kind, xform; };
+// Gives the join of per-lane (divergent) branches a block of its own.  Without it the compiler folds that join into the
+// next wave-uniform join (ultimately the loop header), and every scalar merged there -- the cursor, the cached
+// transform id -- is classed divergent and moves to VGPRs with exec-masked branches.
+#define RT_RECONVERGE() asm volatile("")
 
 // ---- the trace stream ---------------------------------------------------------------------------
 // rt_scene_upload re-packs the blob's node / geom tables into one pre-order byte stream of records
-//     [64 B header: box (6 f64) | skip_off | flags + (nprims << 8) | prim0 | prim1] [80 B rt_geom] x nprims
+//     [64 B header: box (6 f64) | skip_off | flags + (record bytes << 16) | prim0 | prim1] [80 B rt_geom] x nprims
 // so that everything a traversal step needs sits in ONE contiguous window.  Each step issues the
 // whole window (header + both geometry slots + the line after them) as back-to-back scalar loads and
 // waits once: a step costs one scalar-cache latency instead of up to three dependent ones (node ->
 // geom 0 -> geom 1), and the trailing bytes are the records the walk visits next when it continues
 // sequentially, so those steps hit the scalar cache.  The loads are inline asm because the compiler
 // sinks ordinary loads to their first use, which re-serialises them.
+#define RT_STREAM_TRI2 4u    /* header flag (stream only): two triangles under the same transform */
 #define RT_STREAM_HDR 64u
 #define RT_STREAM_GEOM 80u
 #define RT_STREAM_PAD 384u  /* readable bytes past the last record: the window over-reads */
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 struct Window { u32x16 h, a, b; u32x8 c; uint32_t p; };
-RT_DEV void window_issue(Window& w, uint64_t addr) {
-    asm volatile("s_load_dwordx16 %0, %5, 0x0\n\t"
-                 "s_load_dwordx16 %1, %5, 0x40\n\t"
-                 "s_load_dwordx16 %2, %5, 0x80\n\t"
-                 "s_load_dwordx8 %3, %5, 0xc0\n\t"
-                 "s_load_dword %4, %5, 0x100"
-                 : "=&s"(w.h), "=&s"(w.a), "=&s"(w.b), "=&s"(w.c), "=&s"(w.p) : "s"(addr));
+RT_DEV void window_issue(Window& w, uint64_t base, uint32_t off) {  // address = base + off + imm: no per-step address arithmetic
+    asm volatile("s_load_dwordx16 %0, %5, %6 offset:0x0\n\t"
+                 "s_load_dwordx16 %1, %5, %6 offset:0x40\n\t"
+                 "s_load_dwordx16 %2, %5, %6 offset:0x80\n\t"
+                 "s_load_dwordx8 %3, %5, %6 offset:0xc0\n\t"
+                 "s_load_dword %4, %5, %6 offset:0x100"
+                 : "=&s"(w.h), "=&s"(w.a), "=&s"(w.b), "=&s"(w.c), "=&s"(w.p) : "s"(base), "s"(off));
 }
-// `touch` is the destination of an earlier fire-and-forget load: it must stay allocated until that load has landed
-RT_DEV void window_wait(Window& w, uint32_t& touch) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w.h), "+s"(w.a), "+s"(w.b), "+s"(w.c), "+s"(w.p), "+s"(touch));
+// The wait directly follows the issue: a destination register of a load still in flight must never be left to the
+// register allocator (a spill or re-use before the data lands would be silently overwritten) -- which is also why
+// there is no fire-and-forget prefetch of the skip target here (tried: it measured slower as well).
+RT_DEV void window_wait(Window& w) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w.h), "+s"(w.a), "+s"(w.b), "+s"(w.c), "+s"(w.p));
 }
-RT_DEV void stream_touch(uint32_t& touch, uint64_t addr) { asm volatile("s_load_dword %0, %1, 0x0" : "=&s"(touch) : "s"(addr)); }
 RT_DEV double sdbl(uint32_t lo, uint32_t hi) { return __builtin_bit_cast(double, ((uint64_t)hi << 32) | (uint64_t)lo); }
 RT_DEV GeomS window_geom0(const Window& w) {  // stream bytes [64, 144)
     GeomS g;
@@ -121,7 +133,6 @@ RT_DEV GeomS window_geom1(const Window& w) {  // stream bytes [144, 224)
 #define RT_RAYS_PER_LANE 1
 template <int R> struct Rays {
     d3 o[R], d[R];       // ray as handed to this traversal level
-    d3 xo[R], xd[R];     // ray in the space of the cached transform (RT_NONE: == o, d)
     double time[R];
     LaneHit h[R];
 };
@@ -133,25 +144,26 @@ RT_DEV bool ray_is_plain(d3 o, d3 inv) {  // box_axis_fast precondition: no NaN 
     return isfinite(o.x) && isfinite(o.y) && isfinite(o.z) && isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z) && inv.x != 0.0 && inv.y != 0.0 && inv.z != 0.0;
 }
 
-template <int LEVEL, bool COUNT, bool INST, int R>
-RT_DEV void test_prim(const SceneDev& sc, uint32_t p, const GeomS& g, const bool (&pass)[R], Rays<R>& ry, double t_min, uint32_t inst_prim,
-                      uint32_t& cached_xf, LaneCount& cnt) {
-    // (xo, xd) always hold the rays in the space of `cached_xf` (RT_NONE = untransformed): transform.rs:25-32 runs once per
-    // (ray, run of primitives under the same matrix) -- the pagoda wraps every triangle in the same translation
-    if (g.xform != cached_xf) {
-        if (g.xform != RT_NONE) {
-            cptr<double> m = as_const(sc.xforms[g.xform].t_inv);
-            double mm[16];
+// transform.rs:25-32: the ray in the space of transform `xform` (RT_NONE: the ray itself)
+template <int R>
+RT_DEV void apply_xform(const SceneDev& sc, uint32_t xform, const Rays<R>& ry, d3 (&xo)[R], d3 (&xd)[R]) {
+    if (xform != RT_NONE) {
+        cptr<double> m = as_const(sc.xforms[xform].t_inv);
+        double mm[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) mm[k] = m[k];
+        for (int k = 0; k < 16; ++k) mm[k] = m[k];
 #pragma unroll
-            for (int r = 0; r < R; ++r) { ry.xo[r] = mat_mul_xyz(mm, ry.o[r], 1.0); ry.xd[r] = mat_mul_xyz(mm, ry.d[r], 0.0); }
-        } else {
+        for (int r = 0; r < R; ++r) { xo[r] = mat_mul_xyz(mm, ry.o[r], 1.0); xd[r] = mat_mul_xyz(mm, ry.d[r], 0.0); }
+    } else {
 #pragma unroll
-            for (int r = 0; r < R; ++r) { ry.xo[r] = ry.o[r]; ry.xd[r] = ry.d[r]; }
-        }
-        cached_xf = g.xform;
+        for (int r = 0; r < R; ++r) { xo[r] = ry.o[r]; xd[r] = ry.d[r]; }
     }
+}
+
+// One primitive against the wave's rays; (xo, xd) are the rays already in the primitive's space.
+template <int LEVEL, bool COUNT, bool INST, int R>
+RT_DEV void test_prim(const SceneDev& sc, uint32_t p, const GeomS& g, const bool (&pass)[R], Rays<R>& ry, const d3 (&xo)[R], const d3 (&xd)[R],
+                      double t_min, uint32_t inst_prim, LaneCount& cnt) {
     if (g.kind == RT_PRIM_TRIANGLE) {
         const d3 v0 = mk(g.d[0], g.d[1], g.d[2]), e1 = mk(g.d[3], g.d[4], g.d[5]), e2 = mk(g.d[6], g.d[7], g.d[8]);
         TriStage st[R];
@@ -159,14 +171,14 @@ RT_DEV void test_prim(const SceneDev& sc, uint32_t p, const GeomS& g, const bool
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if (COUNT) cnt.tri += pass[r] ? 1u : 0u;
-            alive[r] = tri_stage_a(v0, e1, e2, ry.xo[r], ry.xd[r], st[r]) & pass[r];
+            alive[r] = tri_stage_a(v0, e1, e2, xo[r], xd[r], st[r]) & pass[r];
             any_alive |= alive[r];
         }
-        if (__ballot(any_alive) != 0ull) {  // rare: most tested triangles are nowhere near the rays
+        if (__builtin_amdgcn_ballot_w64(any_alive) != 0ull) {  // rare: most tested triangles are nowhere near the rays
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 double t;
-                if (alive[r] && tri_hit_tail(st[r], e1, e2, ry.xd[r], t_min, ry.h[r].best, t)) { ry.h[r].best = t; ry.h[r].prim = p; ry.h[r].inst = inst_prim; }
+                if (alive[r] && tri_hit_tail(st[r], v0, e1, e2, xo[r], xd[r], t_min, ry.h[r].best, t)) { ry.h[r].best = t; ry.h[r].prim = p; ry.h[r].inst = inst_prim; }
             }
         }
     } else if (g.kind == RT_PRIM_SPHERE || g.kind == RT_PRIM_MOVING_SPHERE) {
@@ -176,18 +188,18 @@ RT_DEV void test_prim(const SceneDev& sc, uint32_t p, const GeomS& g, const bool
             d3 c = mk(g.d[0], g.d[1], g.d[2]);
             double radius = g.d[3], t;
             if (g.kind == RT_PRIM_MOVING_SPHERE) { c = moving_center(c, mk(g.d[3], g.d[4], g.d[5]), g.d[6], g.d[7], ry.time[r]); radius = g.d[8]; }
-            if (pass[r] && sphere_hit(c, radius, ry.xo[r], ry.xd[r], t_min, ry.h[r].best, t)) { ry.h[r].best = t; ry.h[r].prim = p; ry.h[r].inst = inst_prim; }
+            if (pass[r] && sphere_hit(c, radius, xo[r], xd[r], t_min, ry.h[r].best, t)) { ry.h[r].best = t; ry.h[r].prim = p; ry.h[r].inst = inst_prim; }
         }
     } else if (g.kind == RT_PRIM_AARECT) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             double t;
-            if (pass[r] && rect_hit(g.d[0], g.d[1], g.d[2], g.d[3], g.d[4], ry.xo[r], ry.xd[r], t_min, ry.h[r].best, t)) { ry.h[r].best = t; ry.h[r].prim = p; ry.h[r].inst = inst_prim; }
+            if (pass[r] && rect_hit(g.d[0], g.d[1], g.d[2], g.d[3], g.d[4], xo[r], xd[r], t_min, ry.h[r].best, t)) { ry.h[r].best = t; ry.h[r].prim = p; ry.h[r].inst = inst_prim; }
         }
     } else if constexpr (LEVEL == 0 && INST) {  // RT_PRIM_INSTANCE: BVHNode object (optionally under a Transformed), main.rs:161-188
         Rays<R> sub;
 #pragma unroll
-        for (int r = 0; r < R; ++r) { sub.o[r] = ry.xo[r]; sub.d[r] = ry.xd[r]; sub.xo[r] = ry.xo[r]; sub.xd[r] = ry.xd[r]; sub.time[r] = ry.time[r]; sub.h[r] = ry.h[r]; }
+        for (int r = 0; r < R; ++r) { sub.o[r] = xo[r]; sub.d[r] = xd[r]; sub.time[r] = ry.time[r]; sub.h[r] = ry.h[r]; }
         traverse<1, COUNT, INST, R>(sc, (uint32_t)g.d[0], (uint32_t)g.d[1], sub, pass, t_min, p, cnt);
 #pragma unroll
         for (int r = 0; r < R; ++r) ry.h[r] = sub.h[r];
@@ -199,34 +211,52 @@ RT_DEV void test_prim(const SceneDev& sc, uint32_t p, const GeomS& g, const bool
 //   * A ray that fails the box of record j sets wait = skip(j); because subtrees nest, any ray that is
 //     NOT active at record i has wait >= skip(i).  Hence the wave goes to the next record if any ray
 //     passed and to skip(i) otherwise -- no cross-lane reduction is needed.
-template <int LEVEL, bool COUNT, bool INST, bool PLAIN, int R>
+//   * The rays are kept in the space of ONE transform (cur_xf) across the inner loop, where they are loop
+//     invariant: transform.rs:25-32 runs once per (ray, run of leaves under the same matrix) -- the pagoda
+//     wraps every triangle in the same translation.  A leaf whose first primitive wants another transform
+//     leaves the inner loop; the outer loop re-derives the rays and re-enters at that record (its box test
+//     is simply repeated: rays that failed it have already moved on, rays that passed pass again).
+// MODE selects the box-test form (all three give the reference's decision, see rt_scene.h):
+//   BOX_LITERAL  bounding_box.rs:27-46 as written (NaN-capable rays / boxes)
+//   BOX_PLAIN    min/max slab form, exact when no NaN can appear
+// (An octant-uniform form -- near/far planes picked by scalar selects, 6 instead of 8 VALU ops per axis -- measured
+// slower: the scalar unit is as loaded as the vector unit in this loop.)
+enum { BOX_LITERAL = 0, BOX_PLAIN = 1 };
+template <int LEVEL, bool COUNT, bool INST, int MODE, int R>
 RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, uint32_t end, Rays<R>& ry, const d3 (&inv)[R], const bool (&active)[R], double t_min,
                           uint32_t inst_prim, LaneCount& cnt) {
     uint32_t wait[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) { wait[r] = active[r] ? first : 0xFFFFFFFFu; ry.xo[r] = ry.o[r]; ry.xd[r] = ry.d[r]; }
-    uint32_t off = first, touch = 0u;
-    uint32_t cached_xf = RT_NONE;
+    for (int r = 0; r < R; ++r) wait[r] = active[r] ? first : 0xFFFFFFFFu;
+    uint32_t off = first, cur_xf = RT_NONE;
     const uint64_t base = (uint64_t)sc.stream;
     while (off < end) {
-        Window w;
-        window_issue(w, base + off);
-        window_wait(w, touch);
-        const uint32_t skip = w.h[12], flags = w.h[13], p0 = w.h[14], p1 = w.h[15];
-        const uint32_t nprims = flags >> 8;
-        const uint32_t next = off + RT_STREAM_HDR + RT_STREAM_GEOM * nprims;
-        if (nprims == 0u) stream_touch(touch, base + skip);  // inner node: warm the skip target while the box tests run
-        const double bmin[3] = {sdbl(w.h[0], w.h[1]), sdbl(w.h[2], w.h[3]), sdbl(w.h[4], w.h[5])};
-        const double bmax[3] = {sdbl(w.h[6], w.h[7]), sdbl(w.h[8], w.h[9]), sdbl(w.h[10], w.h[11])};
-        bool pass[R], any_pass = false;
+        d3 xo[R], xd[R];
+        apply_xform<R>(sc, cur_xf, ry, xo, xd);
+        uint32_t want = cur_xf;
+        while (off < end) {
+            Window w;
+#ifdef RT_TRACE_DIAG
+            const uint64_t c0 = __builtin_readcyclecounter();
+#endif
+            window_issue(w, base, off);
+            window_wait(w);
+#ifdef RT_TRACE_DIAG
+            cnt.cyc_wait += __builtin_readcyclecounter() - c0; cnt.steps += 1; cnt.leaf_steps += (w.h[13] >> 16) > RT_STREAM_HDR ? 1u : 0u;
+#endif
+            const uint32_t skip = w.h[12], rec = w.h[13];
+            const double bmin[3] = {sdbl(w.h[0], w.h[1]), sdbl(w.h[2], w.h[3]), sdbl(w.h[4], w.h[5])};
+            const double bmax[3] = {sdbl(w.h[6], w.h[7]), sdbl(w.h[8], w.h[9]), sdbl(w.h[10], w.h[11])};
+            bool pass[R], any_pass = false;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const bool act = wait[r] <= off;
-            pass[r] = act;
-            if (!(flags & RT_NODE_NO_BOX)) {
-                if (COUNT) cnt.box += act ? 1u : 0u;
+            for (int r = 0; r < R; ++r) {
+                const bool act = wait[r] <= off;
+                // list items (hittable.rs:41-53, no box in the reference) carry a (-inf, +inf) box in the stream: under the
+                // PLAIN preconditions (finite origin, finite non-zero 1/dir) it passes for every ray, so those
+                // loops need no per-step flag test; the literal form and the counters look at the flag
+                if (COUNT) cnt.box += (act && !(rec & RT_NODE_NO_BOX)) ? 1u : 0u;
                 bool bx, by, bz;
-                if (PLAIN) {
+                if (MODE == BOX_PLAIN) {
                     bx = box_axis_fast(bmin[0], bmax[0], ry.o[r].x, inv[r].x, t_min, ry.h[r].best);
                     by = box_axis_fast(bmin[1], bmax[1], ry.o[r].y, inv[r].y, t_min, ry.h[r].best);
                     bz = box_axis_fast(bmin[2], bmax[2], ry.o[r].z, inv[r].z, t_min, ry.h[r].best);
@@ -234,31 +264,75 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, uint32_t end, Rays
                     bx = box_axis(bmin[0], bmax[0], ry.o[r].x, inv[r].x, t_min, ry.h[r].best);
                     by = box_axis(bmin[1], bmax[1], ry.o[r].y, inv[r].y, t_min, ry.h[r].best);
                     bz = box_axis(bmin[2], bmax[2], ry.o[r].z, inv[r].z, t_min, ry.h[r].best);
+                    if (rec & RT_NODE_NO_BOX) bx = by = bz = true;
                 }
                 pass[r] = act & bx & by & bz;
+                wait[r] = (act & !pass[r]) ? skip : wait[r];
+                any_pass |= pass[r];
             }
-            wait[r] = (act & !pass[r]) ? skip : wait[r];
-            any_pass |= pass[r];
-        }
-        const bool any = __ballot(any_pass) != 0ull;
-        if (nprims != 0u && any) {
-            const GeomS g0 = window_geom0(w);
-            test_prim<LEVEL, COUNT, INST, R>(sc, p0, g0, pass, ry, t_min, inst_prim, cached_xf, cnt);
-            if (nprims > 1u) {
-                const GeomS g1 = window_geom1(w);
-                test_prim<LEVEL, COUNT, INST, R>(sc, p1, g1, pass, ry, t_min, inst_prim, cached_xf, cnt);
-            }
-            if (COUNT && (flags & RT_NODE_DUP_RIGHT)) {  // reference-order count of the skipped duplicate test
+            if (__builtin_amdgcn_ballot_w64(any_pass) == 0ull) {
+                off = skip;
+            } else if (rec < ((RT_STREAM_HDR + 1u) << 16)) {
+                off += RT_STREAM_HDR;
+            } else {
+                const uint32_t p0 = w.h[14], p1 = w.h[15];
+                const GeomS g0 = window_geom0(w);
+                if (g0.xform != cur_xf) {  // re-enter at this record with the rays in the leaf's space
+                    if (COUNT && !(rec & RT_NODE_NO_BOX)) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    if (g0.kind == RT_PRIM_TRIANGLE) cnt.tri += pass[r] ? 1u : 0u;
-                    else if (g0.kind == RT_PRIM_SPHERE || g0.kind == RT_PRIM_MOVING_SPHERE) cnt.sph += pass[r] ? 1u : 0u;
+                        for (int r = 0; r < R; ++r) cnt.box -= pass[r] ? 1u : 0u;  // the repeated box test must not count twice
+                    }
+                    want = g0.xform;
+                    break;
+                }
+                off += rec >> 16;
+                if (rec & RT_STREAM_TRI2) {  // the common leaf: both stage-A tests first, one wave vote, then the exact tails in order
+                    const GeomS g1 = window_geom1(w);
+                    const d3 a0 = mk(g0.d[0], g0.d[1], g0.d[2]), a1 = mk(g0.d[3], g0.d[4], g0.d[5]), a2 = mk(g0.d[6], g0.d[7], g0.d[8]);
+                    const d3 b0 = mk(g1.d[0], g1.d[1], g1.d[2]), b1 = mk(g1.d[3], g1.d[4], g1.d[5]), b2 = mk(g1.d[6], g1.d[7], g1.d[8]);
+                    TriStage sa[R], sb[R];
+                    bool la[R], lb[R], any_alive = false;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        if (COUNT) cnt.tri += pass[r] ? 2u : 0u;
+                        la[r] = tri_stage_a(a0, a1, a2, xo[r], xd[r], sa[r]) & pass[r];
+                        lb[r] = tri_stage_a(b0, b1, b2, xo[r], xd[r], sb[r]) & pass[r];
+                        any_alive |= la[r] | lb[r];
+                    }
+                    if (__builtin_amdgcn_ballot_w64(any_alive) != 0ull) {  // rare: most tested triangles are nowhere near the rays
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            double t;
+                            if (la[r] && tri_hit_tail(sa[r], a0, a1, a2, xo[r], xd[r], t_min, ry.h[r].best, t)) { ry.h[r].best = t; ry.h[r].prim = p0; ry.h[r].inst = inst_prim; }
+                            if (lb[r] && tri_hit_tail(sb[r], b0, b1, b2, xo[r], xd[r], t_min, ry.h[r].best, t)) { ry.h[r].best = t; ry.h[r].prim = p1; ry.h[r].inst = inst_prim; }
+                        }
+                        RT_RECONVERGE();
+                    }
+                } else {
+                    test_prim<LEVEL, COUNT, INST, R>(sc, p0, g0, pass, ry, xo, xd, t_min, inst_prim, cnt);
+                    if (rec >= ((RT_STREAM_HDR + RT_STREAM_GEOM + 1u) << 16)) {
+                        const GeomS g1 = window_geom1(w);
+                        if (g1.xform == cur_xf) {
+                            test_prim<LEVEL, COUNT, INST, R>(sc, p1, g1, pass, ry, xo, xd, t_min, inst_prim, cnt);
+                        } else {  // second primitive of a leaf under a different matrix: one-off transform
+                            d3 yo[R], yd[R];
+                            apply_xform<R>(sc, g1.xform, ry, yo, yd);
+                            test_prim<LEVEL, COUNT, INST, R>(sc, p1, g1, pass, ry, yo, yd, t_min, inst_prim, cnt);
+                        }
+                    }
+                    if (COUNT && (rec & RT_NODE_DUP_RIGHT)) {  // reference-order count of the skipped duplicate test
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            if (g0.kind == RT_PRIM_TRIANGLE) cnt.tri += pass[r] ? 1u : 0u;
+                            else if (g0.kind == RT_PRIM_SPHERE || g0.kind == RT_PRIM_MOVING_SPHERE) cnt.sph += pass[r] ? 1u : 0u;
+                        }
+                    }
+                    RT_RECONVERGE();
                 }
             }
         }
-        off = any ? next : skip;
+        cur_xf = (uint32_t)__builtin_amdgcn_readfirstlane((int)want);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(touch));  // the last touch load must land before its register is reused
 }
 
 template <int LEVEL, bool COUNT, bool INST, int R>
@@ -271,9 +345,9 @@ RT_DEV void traverse(const SceneDev& sc, uint32_t first, uint32_t end, Rays<R>& 
         odd |= active[r] && !(ray_is_plain(ry.o[r], inv[r]) && t_min <= ry.h[r].best);
     }
     // the min/max form of the slab test is exact unless a NaN can appear (zero / non-finite direction or origin): decided per wave
-    const bool plain = sc.boxes_finite && __ballot(odd) == 0ull;
-    if (plain) traverse_impl<LEVEL, COUNT, INST, true, R>(sc, first, end, ry, inv, active, t_min, inst_prim, cnt);
-    else traverse_impl<LEVEL, COUNT, INST, false, R>(sc, first, end, ry, inv, active, t_min, inst_prim, cnt);
+    const bool plain = sc.boxes_finite && __builtin_amdgcn_ballot_w64(odd) == 0ull;
+    if (plain) traverse_impl<LEVEL, COUNT, INST, BOX_PLAIN, R>(sc, first, end, ry, inv, active, t_min, inst_prim, cnt);
+    else traverse_impl<LEVEL, COUNT, INST, BOX_LITERAL, R>(sc, first, end, ry, inv, active, t_min, inst_prim, cnt);
 }
 
 // rays: SoA [7][cap] (ox,oy,oz,dx,dy,dz,time) indexed by path; outputs indexed by path.
@@ -306,7 +380,17 @@ __global__ __launch_bounds__(256) void k_trace(SceneDev sc, const uint32_t* __re
         ry.h[r].best = t_max; ry.h[r].prim = RT_NONE; ry.h[r].inst = RT_NONE;
     }
     LaneCount cnt; cnt.box = cnt.tri = cnt.sph = 0;
+#ifdef RT_TRACE_DIAG
+    cnt.steps = cnt.leaf_steps = cnt.cyc_wait = 0; cnt.cyc_total = __builtin_readcyclecounter();
+#endif
     traverse<0, COUNT, INST, R>(sc, sc.root_off, sc.root_end_off, ry, valid, t_min, RT_NONE, cnt);
+#ifdef RT_TRACE_DIAG
+    cnt.cyc_total = __builtin_readcyclecounter() - cnt.cyc_total;
+    if (stats && lane_id() == 0) {
+        atomicAdd(&stats[4], (unsigned long long)cnt.steps); atomicAdd(&stats[5], (unsigned long long)cnt.leaf_steps);
+        atomicAdd(&stats[6], (unsigned long long)cnt.cyc_wait); atomicAdd(&stats[7], (unsigned long long)cnt.cyc_total); atomicAdd(&stats[8], 1ull);
+    }
+#endif
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         if (valid[r]) {
@@ -668,7 +752,7 @@ static int ws_ensure(rt_scene* sc, uint32_t cap, int32_t depth) {
     WS(ws.pb.path_pixel, cap) WS(ws.pb.path_sample, cap) WS(ws.pb.nb, cap)
     WS(ws.pb.terminal, 3 * (size_t)cap) WS(ws.pb.radiance, 3 * (size_t)cap)
     WS(ws.pb.records, (size_t)std::max(depth, 1) * REC_FIELDS * cap)
-    WS(ws.queue[0], cap) WS(ws.queue[1], cap) WS(ws.shadow_queue, cap) WS(ws.counts, 4) WS(ws.stats, 4)
+    WS(ws.queue[0], cap) WS(ws.queue[1], cap) WS(ws.shadow_queue, cap) WS(ws.counts, 4) WS(ws.stats, 16)
     WS(ws.in_pixel, cap) WS(ws.in_sample, cap)
     WS(ws.raw_queue, cap) WS(ws.raw_keys, cap) WS(ws.raw_squeue, cap) WS(ws.raw_skeys, cap) WS(ws.sorted_keys, cap)
     {
@@ -860,7 +944,8 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     if (h.root_node > h.root_end || h.root_end > h.n_nodes) return fail(RT_ERR_BAD_BLOB, "root range out of bounds");
     bool boxes_finite = true;
     for (uint32_t i = 0; i < h.n_nodes; ++i) {
-        for (int k = 0; k < 3; ++k) boxes_finite = boxes_finite && std::isfinite(nodes[i].bmin[k]) && std::isfinite(nodes[i].bmax[k]);
+        for (int k = 0; k < 3 && !(nodes[i].flags & RT_NODE_NO_BOX); ++k)
+            boxes_finite = boxes_finite && std::isfinite(nodes[i].bmin[k]) && std::isfinite(nodes[i].bmax[k]) && nodes[i].bmin[k] <= nodes[i].bmax[k];
         if (nodes[i].skip <= i || nodes[i].skip > h.n_nodes) return fail(RT_ERR_BAD_BLOB, "node skip link not strictly forward / out of range");
         if ((nodes[i].prim0 != RT_NONE && nodes[i].prim0 >= h.n_prims) || (nodes[i].prim1 != RT_NONE && nodes[i].prim1 >= h.n_prims))
             return fail(RT_ERR_BAD_BLOB, "node primitive index out of range");
@@ -933,8 +1018,17 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     for (uint32_t i = 0; i < h.n_nodes; ++i) {
         uint8_t* rec = stream.data() + rec_off[i];
         const uint32_t np = (nodes[i].prim0 != RT_NONE) + (nodes[i].prim1 != RT_NONE);
-        const uint32_t words[4] = {(uint32_t)rec_off[nodes[i].skip], (nodes[i].flags & 0xFFu) | (np << 8), nodes[i].prim0, nodes[i].prim1};
-        memcpy(rec, nodes[i].bmin, 24); memcpy(rec + 24, nodes[i].bmax, 24); memcpy(rec + 48, words, 16);
+        uint32_t fl = nodes[i].flags & (RT_NODE_NO_BOX | RT_NODE_DUP_RIGHT);
+        if (np == 2 && geom[nodes[i].prim0].kind == RT_PRIM_TRIANGLE && geom[nodes[i].prim1].kind == RT_PRIM_TRIANGLE &&
+            geom[nodes[i].prim0].xform == geom[nodes[i].prim1].xform) fl |= RT_STREAM_TRI2;
+        const uint32_t words[4] = {(uint32_t)rec_off[nodes[i].skip], fl | ((RT_STREAM_HDR + RT_STREAM_GEOM * np) << 16), nodes[i].prim0, nodes[i].prim1};
+        double lo[3], hi[3];
+        for (int k = 0; k < 3; ++k) {  // list items have no box in the reference: see traverse_impl
+            const bool nb = (nodes[i].flags & RT_NODE_NO_BOX) != 0;
+            lo[k] = nb ? -std::numeric_limits<double>::infinity() : nodes[i].bmin[k];
+            hi[k] = nb ? std::numeric_limits<double>::infinity() : nodes[i].bmax[k];
+        }
+        memcpy(rec, lo, 24); memcpy(rec + 24, hi, 24); memcpy(rec + 48, words, 16);
         uint32_t slot = 0;
         for (uint32_t q : {nodes[i].prim0, nodes[i].prim1}) {
             if (q == RT_NONE) continue;
@@ -1013,8 +1107,21 @@ int rt_trace_closest_device(rt_scene* sc, uint32_t n, const double* rays_dev, do
     if (rc != RT_OK) return rc;
     hipStream_t st = sc->ctx->stream;
     hipLaunchKernelGGL(k_aos_to_soa, grid_for(n), dim3(256), 0, st, rays_dev, n, sc->ws.pb.rays, sc->ws.cap);
+#ifdef RT_TRACE_DIAG
+    HIP_OK(hipMemsetAsync(sc->ws.stats, 0, 16 * sizeof(unsigned long long), st));
+#endif
     launch_trace(sc, false, nullptr, nullptr, n, sc->ws.pb.rays, t_min, t_max, prim_id_dev, nullptr, t_dev);
     HIP_OK(hipGetLastError());
+#ifdef RT_TRACE_DIAG
+    {
+        unsigned long long d[16];
+        HIP_OK(hipMemcpyAsync(d, sc->ws.stats, sizeof d, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        const double w = (double)std::max(d[8], 1ull);
+        fprintf(stderr, "[diag] waves %llu  steps/wave %.0f  leaf steps/wave %.0f  cycles/wave %.0f  wait cycles/wave %.0f  cycles/step %.0f  wait/step %.0f\n",
+                d[8], d[4] / w, d[5] / w, d[7] / w, d[6] / w, (double)d[7] / std::max(d[4], 1ull), (double)d[6] / std::max(d[4], 1ull));
+    }
+#endif
     return RT_OK;
 }
 

@@ -92,12 +92,13 @@ RT_DEV bool tri_hit(d3 v0, d3 edge1, d3 edge2, d3 o, d3 d, double t_min, double 
 //        underflowed to -0 would pass `u >= 0`, hence the magnitude floor);
 //   (R2) |s.h| > RN(|det| * (1 + 2^-40))  =>  |det_inv * s.h| > (1 + 2^-41)(1 - 2^-53) > 1  =>  u < 0 or u > 1.
 // Everything not rejected here is decided by the literal code of tri_hit_tail.
-struct TriStage { d3 h, s; double det, sh; };
+// Only det and s.h stay live between the stages (4 VGPRs per triangle); the rare tail recomputes s = o - v0.
+struct TriStage { double det, sh; };
 RT_DEV bool tri_stage_a(d3 v0, d3 edge1, d3 edge2, d3 o, d3 d, TriStage& st) {
-    st.h = cross(d, edge2);
-    st.det = dot(edge1, st.h);
-    st.s = o - v0;
-    st.sh = dot(st.s, st.h);
+    const d3 h = cross(d, edge2);
+    st.det = dot(edge1, h);
+    const d3 s = o - v0;
+    st.sh = dot(s, h);
     const double ad = fabs(st.det);
     const bool e_ok = ad >= F64_EPS;
     const bool in_range = ad <= 1e100;
@@ -105,11 +106,11 @@ RT_DEV bool tri_stage_a(d3 v0, d3 edge1, d3 edge2, d3 o, d3 d, TriStage& st) {
     const bool r2 = fabs(st.sh) > ad * 1.0000000000009094947;  // 1 + 2^-40
     return e_ok & !(in_range & (r1 | r2));
 }
-RT_DEV bool tri_hit_tail(const TriStage& st, d3 edge1, d3 edge2, d3 d, double t_min, double t_max, double& t_out) {
+RT_DEV bool tri_hit_tail(const TriStage& st, d3 v0, d3 edge1, d3 edge2, d3 o, d3 d, double t_min, double t_max, double& t_out) {
     double det_inv = 1.0 / st.det;
     double u = det_inv * st.sh;
     if (!(u >= 0.0 && u <= 1.0)) return false;
-    d3 q = cross(st.s, edge1);
+    d3 q = cross(o - v0, edge1);
     double v = det_inv * dot(d, q);
     if (v < 0.0 || (u + v) > 1.0) return false;
     double t = det_inv * dot(edge2, q);
