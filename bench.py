@@ -3,7 +3,9 @@
 Mrays/s (+ paths/s) on the pagoda OBJ scene, 1920x1080, BRDF (cosine) sampling, depth 5.
 
 A "step" is one pass of the hot path (rt_render: ray-gen -> [traverse -> shade] x depth -> unwind ->
-accumulate) over --spp-per-step samples of every pixel; 25 steps x 4 spp is the config's 100 spp.
+accumulate) over --spp-per-step samples of every pixel (default 16: 33M paths in flight, ~20 GB of the
+288 GB HBM -- large passes keep the thin deeper bounces from being launch-latency bound); 6 steps
+are about the config's 100 spp.
 Inputs (the flattened scene) are resident in HBM before the timed region; accumulators stay on the
 device.  With N ranks each rank renders its own disjoint sample range (weak scaling) and the fp32
 accumulators are all-reduced over RCCL inside the timed region.
@@ -44,11 +46,11 @@ F_BOX, F_TRI, F_SPH = 12, 39, 25
 
 def cpu_baseline(desc, integrator, depth, threads):
     """The oracle (a port: the reference is Rust, no toolchain here) on a bounded sample of the same
-    workload: same scene and camera at 240x135, 2 spp -- rates per ray do not depend on resolution."""
+    workload: same scene and camera at 480x270, 4 spp (about 10-20 s of CPU work) -- rates per ray do not depend on resolution."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_ffi as orc
     osc = orc.OracleScene(desc)
-    w, h, spp = 240, 135, 2
+    w, h, spp = 480, 270, 4
     _, st = osc.render(w, h, 0, spp, depth, integrator, seed=0x5EED, nthreads=threads)
     return {"value": st["rays"] / st["seconds"] / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": f"same scene/camera/integrator at {w}x{h}, {spp} spp: {st['rays']} rays, {st['paths']} paths in {st['seconds']:.2f} s "
@@ -63,7 +65,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="pagoda_1080p_brdf", choices=sorted(WORKLOADS))
-    ap.add_argument("--spp-per-step", type=int, default=4)
+    ap.add_argument("--spp-per-step", type=int, default=16)
     ap.add_argument("--bvh-seed", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)

@@ -71,7 +71,7 @@ struct LaneHit {
 struct LaneCount {
     uint32_t box, tri, sph;
 #ifdef RT_TRACE_DIAG  // diagnostic build only (make diag): wave-level step counts and s_memtime cycle stamps
-    uint64_t steps, leaf_steps, cyc_wait, cyc_total;
+    uint64_t steps, leaf_steps, cyc_wait, cyc_total, lane_steps;
 #endif
 };
 
@@ -251,6 +251,9 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, uint32_t end, Rays
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const bool act = wait[r] <= off;
+#ifdef RT_TRACE_DIAG
+                cnt.lane_steps += act ? 1u : 0u;
+#endif
                 // list items (hittable.rs:41-53, no box in the reference) carry a (-inf, +inf) box in the stream: under the
                 // PLAIN preconditions (finite origin, finite non-zero 1/dir) it passes for every ray, so those
                 // loops need no per-step flag test; the literal form and the counters look at the flag
@@ -381,12 +384,17 @@ __global__ __launch_bounds__(256) void k_trace(SceneDev sc, const uint32_t* __re
     }
     LaneCount cnt; cnt.box = cnt.tri = cnt.sph = 0;
 #ifdef RT_TRACE_DIAG
-    cnt.steps = cnt.leaf_steps = cnt.cyc_wait = 0; cnt.cyc_total = __builtin_readcyclecounter();
+    cnt.steps = cnt.leaf_steps = cnt.cyc_wait = cnt.lane_steps = 0; cnt.cyc_total = __builtin_readcyclecounter();
 #endif
     traverse<0, COUNT, INST, R>(sc, sc.root_off, sc.root_end_off, ry, valid, t_min, RT_NONE, cnt);
 #ifdef RT_TRACE_DIAG
     cnt.cyc_total = __builtin_readcyclecounter() - cnt.cyc_total;
+    const uint64_t lane_steps = wave_sum_u64(cnt.lane_steps);
     if (stats && lane_id() == 0) {
+        atomicAdd(&stats[9], (unsigned long long)lane_steps);
+        atomicMax(&stats[10], (unsigned long long)cnt.steps);
+        if (cnt.steps > 12000) atomicAdd(&stats[11], 1ull);
+        if (cnt.steps > 20000) atomicAdd(&stats[12], 1ull);
         atomicAdd(&stats[4], (unsigned long long)cnt.steps); atomicAdd(&stats[5], (unsigned long long)cnt.leaf_steps);
         atomicAdd(&stats[6], (unsigned long long)cnt.cyc_wait); atomicAdd(&stats[7], (unsigned long long)cnt.cyc_total); atomicAdd(&stats[8], 1ull);
     }
@@ -408,13 +416,28 @@ __global__ __launch_bounds__(256) void k_trace(SceneDev sc, const uint32_t* __re
 // ------------------------------------------------------------------------------------------------
 // k_raygen: main.rs:996-999 + camera.rs:83-101
 // ------------------------------------------------------------------------------------------------
+// Slot -> pixel permutation of one sample layer: the 8-aligned part of the frame in 8x8 tiles (a wave of
+// primary rays is then a square pixel block, whose rays share far more of the walk than a 64x1 strip),
+// the right and bottom remainders row-major.  Results are keyed on the pixel, not the slot.
+RT_DEV uint32_t tiled_pixel(uint32_t q, uint32_t width, uint32_t height) {
+    const uint32_t w8 = width & ~7u, h8 = height & ~7u;
+    if (q < w8 * h8) {
+        const uint32_t tile = q >> 6, i = q & 63u, tpr = w8 >> 3;
+        return ((tile / tpr) * 8u + (i >> 3)) * width + (tile % tpr) * 8u + (i & 7u);
+    }
+    uint32_t r = q - w8 * h8;
+    const uint32_t rw = width - w8;
+    if (r < rw * h8) return (r / rw) * width + w8 + r % rw;
+    r -= rw * h8;
+    return (h8 + r / width) * width + r % width;
+}
 __global__ __launch_bounds__(256) void k_raygen(rt_camera cam, uint32_t width, uint32_t height, uint32_t n, uint32_t sample0, uint32_t npix,
                                                 const uint32_t* __restrict__ in_pixel, const uint32_t* __restrict__ in_sample, uint64_t seed,
                                                 double* __restrict__ rays, uint32_t cap, uint32_t* __restrict__ path_pixel, uint32_t* __restrict__ path_sample,
-                                                uint32_t* __restrict__ nb) {
+                                                uint32_t* __restrict__ nb, uint32_t tiled) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    const uint32_t pixel = in_pixel ? in_pixel[p] : p % npix;
+    const uint32_t pixel = in_pixel ? in_pixel[p] : (tiled ? tiled_pixel(p % npix, width, height) : p % npix);
     const uint32_t sample = in_sample ? in_sample[p] : sample0 + p / npix;
     const uint32_t x = pixel % width, y = pixel / width;
     Rng rng(seed, pixel, sample, 0u);
@@ -648,12 +671,14 @@ __global__ __launch_bounds__(256) void k_unwind(PathBuffers pb, uint32_t n) {
 }
 
 // per pixel: fixed-order f64 sum over this pass's samples, then one fp32 add into the accumulator
-__global__ __launch_bounds__(256) void k_accumulate(const double* __restrict__ radiance, uint32_t cap, uint32_t npix, uint32_t samples, float* __restrict__ accum) {
-    const uint32_t px = blockIdx.x * blockDim.x + threadIdx.x;
-    if (px >= npix) return;
+__global__ __launch_bounds__(256) void k_accumulate(const double* __restrict__ radiance, const uint32_t* __restrict__ path_pixel, uint32_t cap, uint32_t npix, uint32_t samples,
+                                                    float* __restrict__ accum) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;  // slot of the sample layer (k_raygen: every layer uses the same slot -> pixel map)
+    if (q >= npix) return;
+    const uint32_t px = path_pixel[q];
     double r = 0.0, g = 0.0, b = 0.0;
     for (uint32_t s = 0; s < samples; ++s) {
-        size_t p = (size_t)s * npix + px;
+        size_t p = (size_t)s * npix + q;
         r += radiance[0 * (size_t)cap + p]; g += radiance[1 * (size_t)cap + p]; b += radiance[2 * (size_t)cap + p];
     }
     accum[3 * (size_t)px + 0] += (float)r; accum[3 * (size_t)px + 1] += (float)g; accum[3 * (size_t)px + 2] += (float)b;
@@ -802,9 +827,26 @@ static void launch_trace(rt_scene* sc, bool count, const uint32_t* queue, const 
     if (n_bound == 0) return;
 #define RT_LAUNCH_TRACE(C, I) hipLaunchKernelGGL((k_trace<C, I>), grid_for((n_bound + RT_RAYS_PER_LANE - 1) / RT_RAYS_PER_LANE), dim3(256), 0, st, sc->dev, queue, n_ptr, n_bound, rays, sc->ws.cap, t_min, t_max, out_prim, out_inst, out_t, sc->ws.stats)
     const bool inst = sc->has_instances;  // scenes without BVHNode objects use the kernel variant compiled without the nested walk
+#ifdef RT_TRACE_DIAG
+    unsigned long long d0[16];
+    (void)hipMemcpyAsync(d0, sc->ws.stats, sizeof d0, hipMemcpyDeviceToHost, st);
+    (void)hipStreamSynchronize(st);
+#endif
     if (count) { if (inst) RT_LAUNCH_TRACE(true, true); else RT_LAUNCH_TRACE(true, false); }
     else { if (inst) RT_LAUNCH_TRACE(false, true); else RT_LAUNCH_TRACE(false, false); }
 #undef RT_LAUNCH_TRACE
+#ifdef RT_TRACE_DIAG
+    {
+        unsigned long long d[16];
+        (void)hipMemcpyAsync(d, sc->ws.stats, sizeof d, hipMemcpyDeviceToHost, st);
+        (void)hipStreamSynchronize(st);
+        for (int k = 0; k < 16; ++k) if (k != 10) d[k] -= d0[k];
+        (void)hipMemsetAsync(sc->ws.stats + 10, 0, sizeof(unsigned long long), st);
+        const double w = (double)std::max(d[8], 1ull);
+        fprintf(stderr, "[diag] rays %llu waves %llu  steps/wave %.0f  leaf steps/wave %.0f  lane use %.1f%%  cycles/wave %.0f  cycles/step %.0f  wait/step %.0f  max steps %llu  waves>12k %llu  >20k %llu\n",
+                d[0], d[8], d[4] / w, d[5] / w, 100.0 * d[9] / (64.0 * std::max(d[4], 1ull)), d[7] / w, (double)d[7] / std::max(d[4], 1ull), (double)d[6] / std::max(d[4], 1ull), d[10], d[11], d[12]);
+    }
+#endif
 }
 
 // Runs the wavefront loop for n paths whose (pixel, sample) come either from explicit device lists
@@ -825,7 +867,7 @@ static int run_paths(rt_scene* sc, uint32_t n, bool explicit_lists, uint32_t wid
     tm.begin(CAT_OTHER);
     hipLaunchKernelGGL(k_raygen, grid_for(n), dim3(256), 0, st, sc->dev.camera, width, height, n, sample0, npix,
                        explicit_lists ? ws.in_pixel : nullptr, explicit_lists ? ws.in_sample : nullptr, seed, ws.pb.rays, ws.cap, ws.pb.path_pixel,
-                       ws.pb.path_sample, ws.pb.nb);
+                       ws.pb.path_sample, ws.pb.nb, explicit_lists ? 0u : 1u);
     hipLaunchKernelGGL(k_iota, grid_for(n), dim3(256), 0, st, ws.queue[0], n);
     hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, ws.counts + 0, n);
     tm.end();
@@ -1107,21 +1149,8 @@ int rt_trace_closest_device(rt_scene* sc, uint32_t n, const double* rays_dev, do
     if (rc != RT_OK) return rc;
     hipStream_t st = sc->ctx->stream;
     hipLaunchKernelGGL(k_aos_to_soa, grid_for(n), dim3(256), 0, st, rays_dev, n, sc->ws.pb.rays, sc->ws.cap);
-#ifdef RT_TRACE_DIAG
-    HIP_OK(hipMemsetAsync(sc->ws.stats, 0, 16 * sizeof(unsigned long long), st));
-#endif
     launch_trace(sc, false, nullptr, nullptr, n, sc->ws.pb.rays, t_min, t_max, prim_id_dev, nullptr, t_dev);
     HIP_OK(hipGetLastError());
-#ifdef RT_TRACE_DIAG
-    {
-        unsigned long long d[16];
-        HIP_OK(hipMemcpyAsync(d, sc->ws.stats, sizeof d, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipStreamSynchronize(st));
-        const double w = (double)std::max(d[8], 1ull);
-        fprintf(stderr, "[diag] waves %llu  steps/wave %.0f  leaf steps/wave %.0f  cycles/wave %.0f  wait cycles/wave %.0f  cycles/step %.0f  wait/step %.0f\n",
-                d[8], d[4] / w, d[5] / w, d[7] / w, d[6] / w, (double)d[7] / std::max(d[4], 1ull), (double)d[6] / std::max(d[4], 1ull));
-    }
-#endif
     return RT_OK;
 }
 
@@ -1169,7 +1198,7 @@ int rt_primary_rays(rt_scene* sc, uint32_t width, uint32_t height, uint32_t samp
     Workspace& ws = sc->ws;
     hipStream_t st = sc->ctx->stream;
     hipLaunchKernelGGL(k_raygen, grid_for(n), dim3(256), 0, st, sc->dev.camera, width, height, n, sample, n, (const uint32_t*)nullptr, (const uint32_t*)nullptr, seed,
-                       ws.pb.rays, ws.cap, ws.pb.path_pixel, ws.pb.path_sample, (uint32_t*)nullptr);
+                       ws.pb.rays, ws.cap, ws.pb.path_pixel, ws.pb.path_sample, (uint32_t*)nullptr, 0u);
     double* aos = nullptr;
     HIP_OK(hipMalloc((void**)&aos, (size_t)n * 7 * sizeof(double)));
     hipLaunchKernelGGL(k_soa_to_aos, grid_for(n), dim3(256), 0, st, ws.pb.rays, n, ws.cap, aos);
@@ -1210,12 +1239,17 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
         HIP_OK(hipStreamSynchronize(sc->ctx->stream));
         return RT_OK;
     }
-    // paths in flight: bounded by ~4M paths and ~12 GiB of bounce records
+    // paths in flight: as many as fit in a third of the free HBM (at most 64 GiB) and 64M paths.  Large passes matter:
+    // the deeper bounces carry few rays, and every traversal launch lasts at least as long as its slowest wave
+    // (a wave holding one ray that misses everything sweeps the whole trace stream)
     uint32_t spass = p->samples_per_pass;
     if (spass == 0) {
-        uint64_t by_paths = std::max<uint64_t>(1, (4ull << 20) / npix);
-        uint64_t by_mem = std::max<uint64_t>(1, (12ull << 30) / ((uint64_t)npix * ((uint64_t)p->max_depth * REC_FIELDS * 8 + 256)));
-        spass = (uint32_t)std::min<uint64_t>(std::min(by_paths, by_mem), 64);
+        size_t free_b = 0, total_b = 0;
+        HIP_OK(hipMemGetInfo(&free_b, &total_b));
+        const uint64_t budget = std::min<uint64_t>(64ull << 30, (uint64_t)free_b / 3);
+        uint64_t by_paths = std::max<uint64_t>(1, (64ull << 20) / npix);
+        uint64_t by_mem = std::max<uint64_t>(1, budget / ((uint64_t)npix * ((uint64_t)p->max_depth * REC_FIELDS * 8 + 256)));
+        spass = (uint32_t)std::min<uint64_t>(std::min(by_paths, by_mem), 256);
     }
     spass = std::min(spass, spp);
     if ((uint64_t)npix * spass > 0x7FFFFF00ull) return fail(RT_ERR_BAD_ARG, "samples_per_pass * pixels too large");
@@ -1237,7 +1271,7 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
         rc = run_paths(sc, n, false, p->width, p->height, s0, p->max_depth, p->integrator, p->seed, count_tests, sort_rays, tm, launches);
         if (rc != RT_OK) return rc;
         tm.begin(CAT_OTHER);
-        hipLaunchKernelGGL(k_accumulate, grid_for(npix), dim3(256), 0, st, ws.pb.radiance, ws.cap, npix, ns, accum_dev);
+        hipLaunchKernelGGL(k_accumulate, grid_for(npix), dim3(256), 0, st, ws.pb.radiance, ws.pb.path_pixel, ws.cap, npix, ns, accum_dev);
         tm.end();
         launches += 1;
     }
