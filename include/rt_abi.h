@@ -179,6 +179,7 @@ typedef struct rt_stats {
     double ms_shade;     /* sum over shade launches */
     double ms_other;     /* raygen + unwind/accumulate + queue upkeep */
     uint64_t trace_launches;
+    uint64_t filter_violations; /* only with RT_RENDER_COUNT_TESTS: fp32 filter decisions contradicted by the exact f64 test; 0 by construction */
 } rt_stats;
 
 /* number of visible HIP devices (>= 0) or negative error */
@@ -196,7 +197,9 @@ int rt_scene_destroy(rt_scene* scene);
 /* Scene::hit for n rays (scene.rs:31-38).  rays: n x 7 doubles (ox,oy,oz,dx,dy,dz,time), host.
  * Outputs (host): prim_id = object id of the closest primitive or RT_NONE; inst_id = enclosing
  * Transformed object id or RT_NONE (may be NULL); t = ray parameter (0 on miss).
- * counters (host, may be NULL): 3 x u64 = box, triangle, sphere tests summed over the batch. */
+ * counters (host, may be NULL): 4 x u64 = box, triangle, sphere tests summed over the batch (reference order),
+ * then the number of fp32 filter decisions the exact f64 test contradicted (0 by construction: the counting
+ * kernel evaluates both for every decision). */
 int rt_trace_closest(rt_scene* scene, uint32_t n, const double* rays, double t_min, double t_max,
                      uint32_t* prim_id, uint32_t* inst_id, double* t, uint64_t* counters);
 /* Same, everything already resident: rays_dev n x 7 doubles, outputs device arrays; asynchronous on

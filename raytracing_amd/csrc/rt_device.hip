@@ -70,144 +70,275 @@ struct LaneHit {
 };
 struct LaneCount {
     uint32_t box, tri, sph;
+    uint32_t bad;  // COUNT variant only: filter decisions contradicted by the exact test (must stay 0)
 #ifdef RT_TRACE_DIAG  // diagnostic build only (make diag): wave-level step counts and s_memtime cycle stamps
-    uint64_t steps, leaf_steps, cyc_wait, cyc_total, lane_steps;
+    uint64_t steps, leaf_steps, cyc_wait, cyc_total, lane_steps, exact_box, exact_tri;
 #endif
 };
 
 struct GeomS { double d[9]; uint32_t kind, xform; };
+RT_DEV GeomS load_geom(cptr<rt_geom> geom, uint32_t p) {
+    const RT_CONST rt_geom& g = geom[p];
+    GeomS r;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r.d[k] = g.d[k];
+    r.kind = g.kind; r.xform = g.xform;
+    return r;
+}
 // Gives the join of per-lane (divergent) branches a block of its own.  Without it the compiler folds that join into the
 // next wave-uniform join (ultimately the loop header), and every scalar merged there -- the cursor, the cached
 // transform id -- is classed divergent and moves to VGPRs with exec-masked branches.
 #define RT_RECONVERGE() asm volatile("")
 
 // ---- the trace stream ---------------------------------------------------------------------------
-// rt_scene_upload re-packs the blob's node / geom tables into one pre-order byte stream of records
-//     [64 B header: box (6 f64) | skip_off | flags + (record bytes << 16) | prim0 | prim1] [80 B rt_geom] x nprims
-// so that everything a traversal step needs sits in ONE contiguous window.  Each step issues the
-// whole window (header + both geometry slots + the line after them) as back-to-back scalar loads and
-// waits once: a step costs one scalar-cache latency instead of up to three dependent ones (node ->
-// geom 0 -> geom 1), and the trailing bytes are the records the walk visits next when it continues
-// sequentially, so those steps hit the scalar cache.  The loads are inline asm because the compiler
-// sinks ordinary loads to their first use, which re-serialises them.
-#define RT_STREAM_TRI2 4u    /* header flag (stream only): two triangles under the same transform */
-#define RT_STREAM_HDR 64u
-#define RT_STREAM_GEOM 80u
-#define RT_STREAM_PAD 384u  /* readable bytes past the last record: the window over-reads */
+// rt_scene_upload derives from the blob's node / geom tables one pre-order byte stream of FILTER records:
+//     header, 32 B:  fp32 box as (min, max) pairs per axis | skip_off | flags(4) + record bytes/16 (4) + node index (24)
+//     + for a leaf of one triangle (block repeats it) or two under one transform (RT_STREAM_TRI2), 112 B:
+//       xform id | pad | 12 fp32 (A, B) pairs: e2.xyz, ml.xyz = v0 x e2, -n.xyz = -(e1 x e2), E2', ML', N'' (error weights)
+// A traversal step loads one window of the stream (two s_load_dwordx16 + one dwordx2 issued back to back,
+// ONE wait): the header, the triangle block if any, and the line after it, which holds the records the
+// walk visits next when it continues sequentially.  The loads are inline asm because the compiler sinks
+// ordinary loads to their first use, which re-serialises them.
+//
+// The stream only feeds the fp32 FILTERS below.  A filter answers "certainly the reference's decision is
+// pass / fail / reject" or "unknown"; unknown lanes are decided by the exact f64 code on the blob's own
+// tables (nodes[node index], geom[prim]), which is the reference's arithmetic operation for operation.
+// So results never depend on the filters -- only on their error bounds being valid, which the COUNT
+// variant of the kernel re-checks against the exact test for every decision (LaneCount::bad).
+#define RT_STREAM_TRI2 4u      /* header flag (stream only): leaf of one triangle, or two under the same transform, with filter block */
+#define RT_STREAM_LEAF 8u      /* header flag (stream only): record has primitives */
+#define RT_STREAM_REC 32u
+#define RT_STREAM_REC_TRI2 144u
+#define RT_STREAM_PAD 384u     /* readable bytes past the last record: the window over-reads */
+#define RT_STREAM_MAX_NODES (1u << 24)
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
-typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-struct Window { u32x16 h, a, b; u32x8 c; uint32_t p; };
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct Window { u32x16 a, b; u32x2 c; };
 RT_DEV void window_issue(Window& w, uint64_t base, uint32_t off) {  // address = base + off + imm: no per-step address arithmetic
-    asm volatile("s_load_dwordx16 %0, %5, %6 offset:0x0\n\t"
-                 "s_load_dwordx16 %1, %5, %6 offset:0x40\n\t"
-                 "s_load_dwordx16 %2, %5, %6 offset:0x80\n\t"
-                 "s_load_dwordx8 %3, %5, %6 offset:0xc0\n\t"
-                 "s_load_dword %4, %5, %6 offset:0x100"
-                 : "=&s"(w.h), "=&s"(w.a), "=&s"(w.b), "=&s"(w.c), "=&s"(w.p) : "s"(base), "s"(off));
+    asm volatile("s_load_dwordx16 %0, %3, %4 offset:0x0\n\t"
+                 "s_load_dwordx16 %1, %3, %4 offset:0x40\n\t"
+                 "s_load_dwordx2 %2, %3, %4 offset:0x80"
+                 : "=&s"(w.a), "=&s"(w.b), "=&s"(w.c) : "s"(base), "s"(off));
 }
 // The wait directly follows the issue: a destination register of a load still in flight must never be left to the
 // register allocator (a spill or re-use before the data lands would be silently overwritten) -- which is also why
 // there is no fire-and-forget prefetch of the skip target here (tried: it measured slower as well).
-RT_DEV void window_wait(Window& w) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w.h), "+s"(w.a), "+s"(w.b), "+s"(w.c), "+s"(w.p));
+RT_DEV void window_wait(Window& w) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w.a), "+s"(w.b), "+s"(w.c)); }
+template <int K> RT_DEV uint32_t wword(const Window& w) {
+    if constexpr (K < 16) return w.a[K];
+    else if constexpr (K < 32) return w.b[K - 16];
+    else return w.c[K - 32];
 }
-RT_DEV double sdbl(uint32_t lo, uint32_t hi) { return __builtin_bit_cast(double, ((uint64_t)hi << 32) | (uint64_t)lo); }
-RT_DEV GeomS window_geom0(const Window& w) {  // stream bytes [64, 144)
-    GeomS g;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) g.d[k] = sdbl(w.a[2 * k], w.a[2 * k + 1]);
-    g.d[8] = sdbl(w.b[0], w.b[1]); g.kind = w.b[2]; g.xform = w.b[3];
-    return g;
+template <int K> RT_DEV uint64_t wpair(const Window& w) { return ((uint64_t)wword<K + 1>(w) << 32) | (uint64_t)wword<K>(w); }  // dwords K, K+1 as one SGPR pair
+template <int J> RT_DEV uint64_t tri_pair(const Window& w) { return wpair<10 + 2 * J>(w); }
+
+// ---- packed fp32: one instruction evaluates the (A, B) or (min, max) pair held in an SGPR pair against a per-lane
+// value taken from the low (SEL 0) or high (SEL 1) half of a VGPR pair.  op_sel picks the source half for the low
+// result, op_sel_hi for the high result.
+#define PK_MUL(r, s, v, SEL) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0," #SEL "] op_sel_hi:[1," #SEL "]" : "=v"(r) : "s"(s), "v"(v))
+#define PK_FMA_ACC(r, s, v, SEL, acc) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0," #SEL ",0] op_sel_hi:[1," #SEL ",1]" : "=v"(r) : "s"(s), "v"(v), "v"(acc))
+#define PK_FMA_BB(r, s, v, SEL, c, CSEL) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0," #SEL "," #CSEL "] op_sel_hi:[1," #SEL "," #CSEL "]" : "=v"(r) : "s"(s), "v"(v), "v"(c))
+RT_DEV float vmin_f32(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+RT_DEV float vmax_f32(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+RT_DEV float vmax3_f32(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+RT_DEV float vmin3_f32(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+// Lane predicates of the hot path are kept as 64-bit wave masks in SGPR pairs: the compares write them there directly,
+// the scalar unit combines them, and "any lane?" is a scalar compare.  (A ballot of a C++ bool costs a
+// v_cndmask + v_cmp each time.)  Valid only where every lane of the wave is enabled, which holds throughout the walk.
+typedef uint64_t lanemask;
+#define RT_CMP_F32(NAME, OP) RT_DEV lanemask NAME(float a, float b) { lanemask m; asm("v_cmp_" OP "_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
+RT_CMP_F32(mask_le, "le") RT_CMP_F32(mask_ge, "ge") RT_CMP_F32(mask_gt, "gt") RT_CMP_F32(mask_lt, "lt")
+RT_DEV lanemask mask_ge_const(float a, float s) { lanemask m; asm("v_cmp_ge_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "s"(s)); return m; }
+RT_DEV lanemask mask_neg(float a) { lanemask m; asm("v_cmp_gt_f32_e64 %0, 0, %1" : "=s"(m) : "v"(a)); return m; }
+RT_DEV lanemask mask_reached(uint32_t off, uint32_t wait) { lanemask m; asm("v_cmp_ge_u32_e64 %0, %1, %2" : "=s"(m) : "s"(off), "v"(wait)); return m; }
+RT_DEV uint32_t mask_select(uint32_t a, uint32_t b, lanemask m) { uint32_t r; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m)); return r; }  // m ? b : a
+RT_DEV bool mask_lane(lanemask m) { return mask_select(0u, 1u, m) != 0u; }  // this lane's bit (exact paths only)
+
+// double -> float with the result strictly on the stated side (RN conversion errs by <= 2^-24 |x|)
+RT_DEV float f32_below(double v) {
+    if (!(fabs(v) <= 3.0e38)) return v > 0.0 ? 3.0e38f : -__builtin_inff();  // NaN: -inf ("nothing is certainly below")
+    const float f = (float)v;
+    return f - fabsf(f) * 0x1p-22f - 1e-30f;
 }
-RT_DEV GeomS window_geom1(const Window& w) {  // stream bytes [144, 224)
-    GeomS g;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) g.d[k] = sdbl(w.b[4 + 2 * k], w.b[5 + 2 * k]);
-    g.d[6] = sdbl(w.c[0], w.c[1]); g.d[7] = sdbl(w.c[2], w.c[3]); g.d[8] = sdbl(w.c[4], w.c[5]); g.kind = w.c[6]; g.xform = w.c[7];
-    return g;
+RT_DEV float f32_above(double v) {
+    if (!(fabs(v) <= 3.0e38)) return v < 0.0 ? -3.0e38f : __builtin_inff();
+    const float f = (float)v;
+    return f + fabsf(f) * 0x1p-22f + 1e-30f;
 }
 
-// Each lane carries R rays (R = RT_RAYS_PER_LANE): a wave walks the node array once for 64*R rays, so the
-// wave-uniform work per node (scalar loads, cursor, branches -- all issued on the CU's single scalar
-// unit) is amortised over R box tests per lane, and the R independent tests give the VALU ILP.
-#define RT_RAYS_PER_LANE 1
-template <int R> struct Rays {
-    d3 o[R], d[R];       // ray as handed to this traversal level
-    double time[R];
-    LaneHit h[R];
+// ---- box filter --------------------------------------------------------------------------------------------------
+// Exact decision (box_axis_fast, PLAIN rays): pass <=> max_k near_k <= best  and  min_k far_k >= t_min, with
+// near_k / far_k = min / max of the reference's f64 values t = RN(RN(b - o) * inv) for the two planes of axis k.
+// Filter: t' = fma32(b', inv', c') with b' = RN32(b), inv' = RN32(inv), c' = RN32(RN64(-o * inv)).  For finite b:
+//   |t' - t| <= 2^-24 (2.0001 |b inv| + 1.0001 |o inv| + |t|)(1 + 2^-23)  <  0.76 * 2^-22 (|b| + |o|) |inv|
+// so with B >= |b| for every finite box coordinate of the scene,  M = max_k 2^-22 (B + |o_k|) |inv_k|  (rounded up, plus
+// an absolute 1e-30 for fp32 underflow) bounds the error of every plane value, hence of nearmax = max_k min(t'_lo, t'_hi)
+// and farmin = min_k max(t'_lo, t'_hi) (max / min are 1-Lipschitz).  Therefore
+//   nearmax' <= best - M  and  farmin' >= t_min + M   =>  the exact test passes      (thresholds rounded inward)
+//   nearmax' >  best + M  or   farmin' <  t_min - M   =>  the exact test fails       (thresholds rounded outward)
+// and anything else (including every NaN) is "unknown".  fp32 subnormal inputs would add errors the bound does not
+// cover, so rays with an |inv_k| or |o_k| outside [1e-30, 1e30] or a bound above 1e30 (and scenes with B outside that range)
+// get M = +inf: never certain.
+// List items carry a (-inf, +inf) box: t' = -inf / +inf exactly as in f64, "certain pass" (PLAIN rays cannot fail them).
+struct BoxFilter {
+    f2 inv_xy, invz_cx, c_yz;  // (inv.x, inv.y) (inv.z, c.x) (c.y, c.z)
+    float M, hiP, hiF, loP, loF;
+};
+RT_DEV void box_filter_set_best(BoxFilter& f, double best) { f.hiP = f32_below(best - (double)f.M); f.hiF = f32_above(best + (double)f.M); }
+RT_DEV void box_filter_init(BoxFilter& f, d3 o, d3 inv, double t_min, double best, double box_abs_max) {
+    const double cx = -(o.x * inv.x), cy = -(o.y * inv.y), cz = -(o.z * inv.z);
+    f.inv_xy = (f2){(float)inv.x, (float)inv.y}; f.invz_cx = (f2){(float)inv.z, (float)cx}; f.c_yz = (f2){(float)cy, (float)cz};
+    const double ax = fabs(inv.x), ay = fabs(inv.y), az = fabs(inv.z), ox = fabs(o.x), oy = fabs(o.y), oz = fabs(o.z);
+    const bool in_range = fmin(fmin(ax, ay), az) >= 1e-30 && fmax(fmax(ax, ay), az) <= 1e30 && fmax(fmax(ox, oy), oz) <= 1e30 &&
+                          box_abs_max >= 1e-30 && box_abs_max <= 1e30;
+    const double m = fmax(fmax((box_abs_max + ox) * ax, (box_abs_max + oy) * ay), (box_abs_max + oz) * az) * 0x1p-22;
+    // m <= 1e30 keeps every b' inv' and c' far below the fp32 overflow threshold: no inf - inf, hence no NaN for a min / max to drop
+    f.M = (in_range && m <= 1e30) ? f32_above(m) : __builtin_inff();
+    box_filter_set_best(f, best);
+    f.loP = f32_above(t_min + (double)f.M); f.loF = f32_below(t_min - (double)f.M);
+}
+// returns certain-pass / certain-fail lane masks
+RT_DEV void box_filter(const BoxFilter& f, const Window& w, lanemask& cp, lanemask& cf) {
+    f2 tx, ty, tz;
+    PK_FMA_BB(tx, wpair<0>(w), f.inv_xy, 0, f.invz_cx, 1);
+    PK_FMA_BB(ty, wpair<2>(w), f.inv_xy, 1, f.c_yz, 0);
+    PK_FMA_BB(tz, wpair<4>(w), f.invz_cx, 0, f.c_yz, 1);
+    const float nearmax = vmax3_f32(vmin_f32(tx.x, tx.y), vmin_f32(ty.x, ty.y), vmin_f32(tz.x, tz.y));
+    const float farmin = vmin3_f32(vmax_f32(tx.x, tx.y), vmax_f32(ty.x, ty.y), vmax_f32(tz.x, tz.y));
+    cp = mask_le(nearmax, f.hiP) & mask_ge(farmin, f.loP);
+    cf = mask_gt(nearmax, f.hiF) | mask_lt(farmin, f.loF);
+}
+
+// ---- triangle filter -----------------------------------------------------------------------------------------------
+// The reference rejects a triangle unless u = RN(RN(1/det) * sh) lies in [0, 1], where det = e1.(d x e2) and
+// sh = (o - v0).(d x e2) are its rounded f64 values (mesh.rs:57-66).  In real arithmetic det = d.(-n) with n = e1 x e2 and
+// sh = e2.(o x d) + d.(v0 x e2).  The filter evaluates these two dot products in fp32 for both triangles of the leaf
+// at once (mo = RN32(RN64(o x d)), ml = RN32(RN64(v0 x e2)), n likewise from the host) and bounds the distance to the
+// reference's values:
+//   |sh' - sh_ref|  <= 8 * 2^-24 (|e2|_inf |mo|_1 + |d|_inf |ml|_1)  +  f64 roundings <= 2^-48 (|o|_inf + |v0|_inf) |d|_inf |e2|_1
+//   |det' - det_ref| <= 5 * 2^-24 |d|_inf |n|_1                        +  f64 roundings <= 2^-48 |d|_inf |e1|_1 |e2|_1
+// (6- and 3-term fp32 dot products by FMA: gamma_6 + 2u per product, Hoelder for the sums).  The stream carries
+//   E2' = 2^-20 |e2|_inf,  ML' = 2^-20 |ml|_1 + 2^-46 |v0|_inf |e2|_1,  N'' = (1 + 2^-19)(2^-20 |n|_1 + 2^-46 |e1|_1 |e2|_1)
+// (each rounded up) and the ray  D = |d|_inf,  MO' = |mo|_1 + 2^-26 |o|_inf |d|_inf  (rounded up), so that
+//   ms = E2' MO' + D ML' >= 2 x the sh bound,   md = D N'' >= 2 x (1 + 2^-19) x the det bound.
+// With a = |sh'| - ms <= |sh_ref|, c = |det'| - md <= |det_ref|, b = RN32(|det'| (1 + 2^-20) + md) >= (1 + 2^-40)|det_ref|:
+//   (R1') a >= 2e-18, c >= 2e-18, sh' det' < 0  =>  sh_ref and det_ref have the signs of sh', det' (opposite), and
+//         sh_ref * det_ref <= -4e-36: premise R1 of tri_stage_a (rt_scene.h) holds unless |det_ref| < EPS  => reject;
+//   (R2') a >= 2e-18, a > b                     =>  |sh_ref| > (1 + 2^-40)|det_ref|: premise R2 holds unless |det_ref| < EPS => reject
+// (|det_ref| <= |det'| + md is finite in fp32, so the 1e100 guard of tri_stage_a holds; |det_ref| < EPS is the
+// reference's own rejection).  The 2e-18 floors keep fp32 underflow (absolute errors <= 1e-37) out of both tests;
+// fp32 overflow gives inf - inf = NaN and no rejection.  Everything not rejected goes to the exact f64 test.
+struct TriFilter { f2 d_xy, dz_mox, mo_yz, D_MO; };
+RT_DEV void tri_filter_init(TriFilter& f, d3 o, d3 d) {
+    const d3 mo = cross(o, d);
+    f.d_xy = (f2){(float)d.x, (float)d.y}; f.dz_mox = (f2){(float)d.z, (float)mo.x}; f.mo_yz = (f2){(float)mo.y, (float)mo.z};
+    const double D = fmax(fmax(fabs(d.x), fabs(d.y)), fabs(d.z)), O = fmax(fmax(fabs(o.x), fabs(o.y)), fabs(o.z));
+    f.D_MO = (f2){f32_above(D), f32_above((fabs(mo.x) + fabs(mo.y)) + fabs(mo.z) + 0x1p-26 * O * D)};
+}
+RT_DEV lanemask tri_filter_one(float sh, float det, float ms, float md) {  // set: certainly rejected by the reference
+    const float a = fabsf(sh) - ms, c = fabsf(det) - md;
+    const float b = __builtin_fmaf(fabsf(det), 1.0f + 0x1p-20f, md);
+    const float p = sh * det;
+    return mask_ge_const(a, 2e-18f) & (mask_gt(a, b) | (mask_ge_const(c, 2e-18f) & mask_neg(p)));
+}
+RT_DEV void tri_filter(const TriFilter& f, const Window& w, lanemask& rejA, lanemask& rejB) {
+    f2 sh, det, ms, md;
+    PK_MUL(sh, tri_pair<0>(w), f.dz_mox, 1);            // e2.x * mo.x
+    PK_FMA_ACC(sh, tri_pair<1>(w), f.mo_yz, 0, sh);     // e2.y * mo.y
+    PK_FMA_ACC(sh, tri_pair<2>(w), f.mo_yz, 1, sh);     // e2.z * mo.z
+    PK_FMA_ACC(sh, tri_pair<3>(w), f.d_xy, 0, sh);      // ml.x * d.x
+    PK_FMA_ACC(sh, tri_pair<4>(w), f.d_xy, 1, sh);      // ml.y * d.y
+    PK_FMA_ACC(sh, tri_pair<5>(w), f.dz_mox, 0, sh);    // ml.z * d.z
+    PK_MUL(det, tri_pair<6>(w), f.d_xy, 0);             // -n.x * d.x
+    PK_FMA_ACC(det, tri_pair<7>(w), f.d_xy, 1, det);    // -n.y * d.y
+    PK_FMA_ACC(det, tri_pair<8>(w), f.dz_mox, 0, det);  // -n.z * d.z
+    PK_MUL(ms, tri_pair<10>(w), f.D_MO, 0);             // ML' * D
+    PK_FMA_ACC(ms, tri_pair<9>(w), f.D_MO, 1, ms);      // E2' * MO'
+    PK_MUL(md, tri_pair<11>(w), f.D_MO, 0);             // N'' * D
+    rejA = tri_filter_one(sh.x, det.x, ms.x, md.x);
+    rejB = tri_filter_one(sh.y, det.y, ms.y, md.y);
+}
+
+struct RayS { d3 o, d; double time; };  // ray as handed to this traversal level
+// Where a traversal level gets its f64 ray from.  Only the fp32 filter state is live across the hot loop; the exact
+// paths (a few percent of the steps) fetch the f64 ray again instead of holding 14 VGPRs per lane for it:
+// the top level parks it in LDS (14 KB per block; the asm keeps the reads inside the rare blocks), an instance
+// level keeps the transformed ray it was handed in registers.
+struct RayFromLds {
+    const double* slot;  // &lds[threadIdx.x]; component c at slot[c * 256]
+    RT_DEV RayS get() const {
+        const double* p = slot;
+        asm volatile("" : "+v"(p));
+        RayS r;
+        r.o = mk(p[0 * 256], p[1 * 256], p[2 * 256]);
+        r.d = mk(p[3 * 256], p[4 * 256], p[5 * 256]);
+        r.time = p[6 * 256];
+        return r;
+    }
+};
+struct RayInRegisters {
+    RayS r;
+    RT_DEV RayS get() const { return r; }
 };
 
-template <int LEVEL, bool COUNT, bool INST, int R>
-RT_DEV void traverse(const SceneDev& sc, uint32_t first, uint32_t end, Rays<R>& ry, const bool (&active)[R], double t_min, uint32_t inst_prim, LaneCount& cnt);
+template <int LEVEL, bool COUNT, bool INST, class RAYSRC>
+RT_DEV void traverse(const SceneDev& sc, uint32_t first, uint32_t end, const RAYSRC& src, LaneHit& h, bool active, double t_min, uint32_t inst_prim, LaneCount& cnt);
 
 RT_DEV bool ray_is_plain(d3 o, d3 inv) {  // box_axis_fast precondition: no NaN can appear in (b - o) * inv
     return isfinite(o.x) && isfinite(o.y) && isfinite(o.z) && isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z) && inv.x != 0.0 && inv.y != 0.0 && inv.z != 0.0;
 }
 
 // transform.rs:25-32: the ray in the space of transform `xform` (RT_NONE: the ray itself)
-template <int R>
-RT_DEV void apply_xform(const SceneDev& sc, uint32_t xform, const Rays<R>& ry, d3 (&xo)[R], d3 (&xd)[R]) {
+RT_DEV void apply_xform(const SceneDev& sc, uint32_t xform, const RayS& ray, d3& xo, d3& xd) {
     if (xform != RT_NONE) {
         cptr<double> m = as_const(sc.xforms[xform].t_inv);
         double mm[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) mm[k] = m[k];
-#pragma unroll
-        for (int r = 0; r < R; ++r) { xo[r] = mat_mul_xyz(mm, ry.o[r], 1.0); xd[r] = mat_mul_xyz(mm, ry.d[r], 0.0); }
+        xo = mat_mul_xyz(mm, ray.o, 1.0); xd = mat_mul_xyz(mm, ray.d, 0.0);
     } else {
-#pragma unroll
-        for (int r = 0; r < R; ++r) { xo[r] = ry.o[r]; xd[r] = ry.d[r]; }
+        xo = ray.o; xd = ray.d;
     }
 }
 
-// One primitive against the wave's rays; (xo, xd) are the rays already in the primitive's space.
-template <int LEVEL, bool COUNT, bool INST, int R>
-RT_DEV void test_prim(const SceneDev& sc, uint32_t p, const GeomS& g, const bool (&pass)[R], Rays<R>& ry, const d3 (&xo)[R], const d3 (&xd)[R],
+// One primitive against the wave's rays (exact f64); (xo, xd) is the ray already in the primitive's space.
+// Returns true if the lane's closest hit changed.
+template <int LEVEL, bool COUNT, bool INST>
+RT_DEV bool test_prim(const SceneDev& sc, uint32_t p, const GeomS& g, bool pass, const RayS& ray, LaneHit& h, d3 xo, d3 xd,
                       double t_min, uint32_t inst_prim, LaneCount& cnt) {
+    bool changed = false;
     if (g.kind == RT_PRIM_TRIANGLE) {
         const d3 v0 = mk(g.d[0], g.d[1], g.d[2]), e1 = mk(g.d[3], g.d[4], g.d[5]), e2 = mk(g.d[6], g.d[7], g.d[8]);
-        TriStage st[R];
-        bool alive[R], any_alive = false;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (COUNT) cnt.tri += pass[r] ? 1u : 0u;
-            alive[r] = tri_stage_a(v0, e1, e2, xo[r], xd[r], st[r]) & pass[r];
-            any_alive |= alive[r];
-        }
-        if (__builtin_amdgcn_ballot_w64(any_alive) != 0ull) {  // rare: most tested triangles are nowhere near the rays
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                double t;
-                if (alive[r] && tri_hit_tail(st[r], v0, e1, e2, xo[r], xd[r], t_min, ry.h[r].best, t)) { ry.h[r].best = t; ry.h[r].prim = p; ry.h[r].inst = inst_prim; }
-            }
+        TriStage st;
+        if (COUNT) cnt.tri += pass ? 1u : 0u;
+        const bool alive = tri_stage_a(v0, e1, e2, xo, xd, st) & pass;
+        if (__builtin_amdgcn_ballot_w64(alive) != 0ull) {  // rare: most tested triangles are nowhere near the rays
+            double t;
+            if (alive && tri_hit_tail(st, v0, e1, e2, xo, xd, t_min, h.best, t)) { h.best = t; h.prim = p; h.inst = inst_prim; changed = true; }
         }
     } else if (g.kind == RT_PRIM_SPHERE || g.kind == RT_PRIM_MOVING_SPHERE) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (COUNT) cnt.sph += pass[r] ? 1u : 0u;
-            d3 c = mk(g.d[0], g.d[1], g.d[2]);
-            double radius = g.d[3], t;
-            if (g.kind == RT_PRIM_MOVING_SPHERE) { c = moving_center(c, mk(g.d[3], g.d[4], g.d[5]), g.d[6], g.d[7], ry.time[r]); radius = g.d[8]; }
-            if (pass[r] && sphere_hit(c, radius, xo[r], xd[r], t_min, ry.h[r].best, t)) { ry.h[r].best = t; ry.h[r].prim = p; ry.h[r].inst = inst_prim; }
-        }
+        if (COUNT) cnt.sph += pass ? 1u : 0u;
+        d3 c = mk(g.d[0], g.d[1], g.d[2]);
+        double radius = g.d[3], t;
+        if (g.kind == RT_PRIM_MOVING_SPHERE) { c = moving_center(c, mk(g.d[3], g.d[4], g.d[5]), g.d[6], g.d[7], ray.time); radius = g.d[8]; }
+        if (pass && sphere_hit(c, radius, xo, xd, t_min, h.best, t)) { h.best = t; h.prim = p; h.inst = inst_prim; changed = true; }
     } else if (g.kind == RT_PRIM_AARECT) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            double t;
-            if (pass[r] && rect_hit(g.d[0], g.d[1], g.d[2], g.d[3], g.d[4], xo[r], xd[r], t_min, ry.h[r].best, t)) { ry.h[r].best = t; ry.h[r].prim = p; ry.h[r].inst = inst_prim; }
-        }
+        double t;
+        if (pass && rect_hit(g.d[0], g.d[1], g.d[2], g.d[3], g.d[4], xo, xd, t_min, h.best, t)) { h.best = t; h.prim = p; h.inst = inst_prim; changed = true; }
     } else if constexpr (LEVEL == 0 && INST) {  // RT_PRIM_INSTANCE: BVHNode object (optionally under a Transformed), main.rs:161-188
-        Rays<R> sub;
-#pragma unroll
-        for (int r = 0; r < R; ++r) { sub.o[r] = xo[r]; sub.d[r] = xd[r]; sub.time[r] = ry.time[r]; sub.h[r] = ry.h[r]; }
-        traverse<1, COUNT, INST, R>(sc, (uint32_t)g.d[0], (uint32_t)g.d[1], sub, pass, t_min, p, cnt);
-#pragma unroll
-        for (int r = 0; r < R; ++r) ry.h[r] = sub.h[r];
+        RayInRegisters sub; sub.r.o = xo; sub.r.d = xd; sub.r.time = ray.time;
+        const double before = h.best;
+        cptr<uint32_t> node_off = as_const(sc.node_off);
+        traverse<1, COUNT, INST, RayInRegisters>(sc, node_off[(uint32_t)g.d[0]], node_off[(uint32_t)g.d[1]], sub, h, pass, t_min, p, cnt);
+        changed = h.best != before;
     }
+    return changed;
 }
 
 // Wave-coherent walk of the stream records in byte range [first, end).
-//   * `off` is the wave-uniform cursor; ray r of a lane takes part in a record iff its private wait[r] is <= off.
+//   * `off` is the wave-uniform cursor; a lane's ray takes part in a record iff its private `wait` is <= off.
 //   * A ray that fails the box of record j sets wait = skip(j); because subtrees nest, any ray that is
 //     NOT active at record i has wait >= skip(i).  Hence the wave goes to the next record if any ray
 //     passed and to skip(i) otherwise -- no cross-lane reduction is needed.
@@ -216,23 +347,45 @@ RT_DEV void test_prim(const SceneDev& sc, uint32_t p, const GeomS& g, const bool
 //     wraps every triangle in the same translation.  A leaf whose first primitive wants another transform
 //     leaves the inner loop; the outer loop re-derives the rays and re-enters at that record (its box test
 //     is simply repeated: rays that failed it have already moved on, rays that passed pass again).
-// MODE selects the box-test form (all three give the reference's decision, see rt_scene.h):
-//   BOX_LITERAL  bounding_box.rs:27-46 as written (NaN-capable rays / boxes)
-//   BOX_PLAIN    min/max slab form, exact when no NaN can appear
-// (An octant-uniform form -- near/far planes picked by scalar selects, 6 instead of 8 VALU ops per axis -- measured
-// slower: the scalar unit is as loaded as the vector unit in this loop.)
+// MODE selects the box-test form:
+//   BOX_LITERAL  bounding_box.rs:27-46 as written, in f64, for NaN-capable rays / boxes
+//   BOX_PLAIN    fp32 filter, with the min/max f64 form (exact when no NaN can appear) for the unknown lanes
+// (An octant-uniform form -- near/far planes picked by scalar selects -- measured slower: the scalar unit is
+// as loaded as the vector unit in this loop.)
 enum { BOX_LITERAL = 0, BOX_PLAIN = 1 };
-template <int LEVEL, bool COUNT, bool INST, int MODE, int R>
-RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, uint32_t end, Rays<R>& ry, const d3 (&inv)[R], const bool (&active)[R], double t_min,
+template <bool PLAIN>
+RT_DEV bool box_exact(cptr<rt_node> nodes, uint32_t node, d3 o, d3 d, double t_min, double best) {
+    const RT_CONST rt_node& nd = nodes[node];
+    const d3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);  // bounding_box.rs:29 (re-derived: not worth three live register pairs)
+    if (nd.flags & RT_NODE_NO_BOX) return true;  // hittable.rs:41-53: list items are tested without a box
+    if (PLAIN)
+        return box_axis_fast(nd.bmin[0], nd.bmax[0], o.x, inv.x, t_min, best) & box_axis_fast(nd.bmin[1], nd.bmax[1], o.y, inv.y, t_min, best) &
+               box_axis_fast(nd.bmin[2], nd.bmax[2], o.z, inv.z, t_min, best);
+    return box_axis(nd.bmin[0], nd.bmax[0], o.x, inv.x, t_min, best) & box_axis(nd.bmin[1], nd.bmax[1], o.y, inv.y, t_min, best) &
+           box_axis(nd.bmin[2], nd.bmax[2], o.z, inv.z, t_min, best);
+}
+
+template <int LEVEL, bool COUNT, bool INST, int MODE, class RAYSRC>
+RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, uint32_t end, const RAYSRC& src, LaneHit& h, bool active, double t_min,
                           uint32_t inst_prim, LaneCount& cnt) {
-    uint32_t wait[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) wait[r] = active[r] ? first : 0xFFFFFFFFu;
+    uint32_t wait = active ? first : 0xFFFFFFFFu;
     uint32_t off = first, cur_xf = RT_NONE;
     const uint64_t base = (uint64_t)sc.stream;
+    cptr<rt_node> nodes = as_const(sc.nodes);
+    cptr<rt_geom> geom = as_const(sc.geom);
+    BoxFilter bf;
+    if (MODE == BOX_PLAIN) {
+        const RayS ray = src.get();
+        box_filter_init(bf, ray.o, mk(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z), t_min, h.best, sc.box_abs_max);
+    }
     while (off < end) {
-        d3 xo[R], xd[R];
-        apply_xform<R>(sc, cur_xf, ry, xo, xd);
+        TriFilter tf;
+        {
+            const RayS ray = src.get();
+            d3 xo, xd;
+            apply_xform(sc, cur_xf, ray, xo, xd);
+            tri_filter_init(tf, xo, xd);
+        }
         uint32_t want = cur_xf;
         while (off < end) {
             Window w;
@@ -241,175 +394,188 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, uint32_t end, Rays
 #endif
             window_issue(w, base, off);
             window_wait(w);
+            const uint32_t skip = wword<6>(w), rec = wword<7>(w);
+            const uint32_t node = rec >> 8;
 #ifdef RT_TRACE_DIAG
-            cnt.cyc_wait += __builtin_readcyclecounter() - c0; cnt.steps += 1; cnt.leaf_steps += (w.h[13] >> 16) > RT_STREAM_HDR ? 1u : 0u;
+            cnt.cyc_wait += __builtin_readcyclecounter() - c0; cnt.steps += 1; cnt.leaf_steps += (rec & RT_STREAM_LEAF) ? 1u : 0u;
 #endif
-            const uint32_t skip = w.h[12], rec = w.h[13];
-            const double bmin[3] = {sdbl(w.h[0], w.h[1]), sdbl(w.h[2], w.h[3]), sdbl(w.h[4], w.h[5])};
-            const double bmax[3] = {sdbl(w.h[6], w.h[7]), sdbl(w.h[8], w.h[9]), sdbl(w.h[10], w.h[11])};
-            bool pass[R], any_pass = false;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const bool act = wait[r] <= off;
+            const lanemask m_act = mask_reached(off, wait);
 #ifdef RT_TRACE_DIAG
-                cnt.lane_steps += act ? 1u : 0u;
+            cnt.lane_steps += mask_lane(m_act) ? 1u : 0u;
 #endif
-                // list items (hittable.rs:41-53, no box in the reference) carry a (-inf, +inf) box in the stream: under the
-                // PLAIN preconditions (finite origin, finite non-zero 1/dir) it passes for every ray, so those
-                // loops need no per-step flag test; the literal form and the counters look at the flag
-                if (COUNT) cnt.box += (act && !(rec & RT_NODE_NO_BOX)) ? 1u : 0u;
-                bool bx, by, bz;
-                if (MODE == BOX_PLAIN) {
-                    bx = box_axis_fast(bmin[0], bmax[0], ry.o[r].x, inv[r].x, t_min, ry.h[r].best);
-                    by = box_axis_fast(bmin[1], bmax[1], ry.o[r].y, inv[r].y, t_min, ry.h[r].best);
-                    bz = box_axis_fast(bmin[2], bmax[2], ry.o[r].z, inv[r].z, t_min, ry.h[r].best);
-                } else {
-                    bx = box_axis(bmin[0], bmax[0], ry.o[r].x, inv[r].x, t_min, ry.h[r].best);
-                    by = box_axis(bmin[1], bmax[1], ry.o[r].y, inv[r].y, t_min, ry.h[r].best);
-                    bz = box_axis(bmin[2], bmax[2], ry.o[r].z, inv[r].z, t_min, ry.h[r].best);
-                    if (rec & RT_NODE_NO_BOX) bx = by = bz = true;
+            if (COUNT) cnt.box += (mask_lane(m_act) && !(rec & RT_NODE_NO_BOX)) ? 1u : 0u;
+            lanemask m_pass;
+            if (MODE == BOX_PLAIN) {
+                lanemask cp, cf;
+                box_filter(bf, w, cp, cf);
+                m_pass = m_act & cp;
+                if (COUNT || (m_act & ~(cp | cf)) != 0ull) {  // rare: a plane value within the error bound of best / t_min
+                    const RayS ray = src.get();
+                    const bool act = mask_lane(m_act);
+                    const bool ex = act & box_exact<true>(nodes, node, ray.o, ray.d, t_min, h.best);
+                    if (COUNT) cnt.bad += (act & ((mask_lane(cp) & !ex) | (mask_lane(cf) & ex))) ? 1u : 0u;
+                    m_pass = __builtin_amdgcn_ballot_w64(ex);
+#ifdef RT_TRACE_DIAG
+                    cnt.exact_box += 1;
+#endif
                 }
-                pass[r] = act & bx & by & bz;
-                wait[r] = (act & !pass[r]) ? skip : wait[r];
-                any_pass |= pass[r];
-            }
-            if (__builtin_amdgcn_ballot_w64(any_pass) == 0ull) {
-                off = skip;
-            } else if (rec < ((RT_STREAM_HDR + 1u) << 16)) {
-                off += RT_STREAM_HDR;
             } else {
-                const uint32_t p0 = w.h[14], p1 = w.h[15];
-                const GeomS g0 = window_geom0(w);
-                if (g0.xform != cur_xf) {  // re-enter at this record with the rays in the leaf's space
-                    if (COUNT && !(rec & RT_NODE_NO_BOX)) {
+                const RayS ray = src.get();
+                m_pass = __builtin_amdgcn_ballot_w64(mask_lane(m_act) & box_exact<false>(nodes, node, ray.o, ray.d, t_min, h.best));
+            }
+            wait = mask_select(wait, skip, m_act & ~m_pass);
+            if (m_pass == 0ull) {
+                off = skip;
+            } else if (!(rec & RT_STREAM_LEAF)) {
+                off += RT_STREAM_REC;
+            } else if (rec & RT_STREAM_TRI2) {  // the common leaf: one or two triangles under one transform
+                if (wword<8>(w) != cur_xf) {  // re-enter at this record with the rays in the leaf's space
+                    if (COUNT && !(rec & RT_NODE_NO_BOX)) cnt.box -= mask_lane(m_pass) ? 1u : 0u;  // the repeated box test must not count twice
+                    want = wword<8>(w);
+                    break;
+                }
+                off += RT_STREAM_REC_TRI2;
+                if (COUNT) {  // reference-order test count: two triangles, or one (tested twice as the duplicated child of a 1-object BVH leaf)
+                    const uint32_t ntests = (nodes[node].prim1 != RT_NONE || (rec & RT_NODE_DUP_RIGHT)) ? 2u : 1u;
+                    cnt.tri += mask_lane(m_pass) ? ntests : 0u;
+                }
+                lanemask rejA, rejB;
+                tri_filter(tf, w, rejA, rejB);
+                if (COUNT || (m_pass & ~(rejA & rejB)) != 0ull) {  // rare: most tested triangles are nowhere near the rays
+                    // exact f64 tests, one triangle at a time (register pressure); the f64 ray is re-derived here
+                    // rather than kept live across the hot loop
+                    const RayS ray = src.get();
+                    d3 xo, xd;
+                    apply_xform(sc, cur_xf, ray, xo, xd);
+                    const bool pass = mask_lane(m_pass);
+                    bool changed = false;
 #pragma unroll
-                        for (int r = 0; r < R; ++r) cnt.box -= pass[r] ? 1u : 0u;  // the repeated box test must not count twice
+                    for (int k = 0; k < 2; ++k) {
+                        const lanemask m_rej = k == 0 ? rejA : rejB;
+                        if (!COUNT && (m_pass & ~m_rej) == 0ull) continue;  // nobody needs this triangle
+                        const uint32_t p = k == 0 ? nodes[node].prim0 : nodes[node].prim1;
+                        if (p == RT_NONE) break;  // single-triangle leaf: its filter block repeats triangle A
+                        const GeomS g = load_geom(geom, p);
+                        const d3 v0 = mk(g.d[0], g.d[1], g.d[2]), e1 = mk(g.d[3], g.d[4], g.d[5]), e2 = mk(g.d[6], g.d[7], g.d[8]);
+                        const bool rej = mask_lane(m_rej);
+                        TriStage st;
+                        double t;
+                        const bool go = pass & (COUNT ? true : !rej) & tri_stage_a(v0, e1, e2, xo, xd, st);
+                        if (go && tri_hit_tail(st, v0, e1, e2, xo, xd, t_min, h.best, t)) {
+                            h.best = t; h.prim = p; h.inst = inst_prim; changed = true;
+                            if (COUNT) cnt.bad += rej ? 1u : 0u;  // a filtered lane must be one the reference rejects
+                        }
                     }
+                    if (MODE == BOX_PLAIN && changed) box_filter_set_best(bf, h.best);
+#ifdef RT_TRACE_DIAG
+                    cnt.exact_tri += 1;
+#endif
+                    RT_RECONVERGE();
+                }
+            } else {  // any other leaf: exact tests on the blob's tables
+                const uint32_t p0 = nodes[node].prim0, p1 = nodes[node].prim1;
+                const GeomS g0 = load_geom(geom, p0);
+                const bool pass = mask_lane(m_pass);
+                if (g0.xform != cur_xf) {
+                    if (COUNT && !(rec & RT_NODE_NO_BOX)) cnt.box -= pass ? 1u : 0u;
                     want = g0.xform;
                     break;
                 }
-                off += rec >> 16;
-                if (rec & RT_STREAM_TRI2) {  // the common leaf: both stage-A tests first, one wave vote, then the exact tails in order
-                    const GeomS g1 = window_geom1(w);
-                    const d3 a0 = mk(g0.d[0], g0.d[1], g0.d[2]), a1 = mk(g0.d[3], g0.d[4], g0.d[5]), a2 = mk(g0.d[6], g0.d[7], g0.d[8]);
-                    const d3 b0 = mk(g1.d[0], g1.d[1], g1.d[2]), b1 = mk(g1.d[3], g1.d[4], g1.d[5]), b2 = mk(g1.d[6], g1.d[7], g1.d[8]);
-                    TriStage sa[R], sb[R];
-                    bool la[R], lb[R], any_alive = false;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        if (COUNT) cnt.tri += pass[r] ? 2u : 0u;
-                        la[r] = tri_stage_a(a0, a1, a2, xo[r], xd[r], sa[r]) & pass[r];
-                        lb[r] = tri_stage_a(b0, b1, b2, xo[r], xd[r], sb[r]) & pass[r];
-                        any_alive |= la[r] | lb[r];
+                off += RT_STREAM_REC;
+                const RayS ray = src.get();
+                d3 xo, xd;
+                apply_xform(sc, cur_xf, ray, xo, xd);
+                bool changed = test_prim<LEVEL, COUNT, INST>(sc, p0, g0, pass, ray, h, xo, xd, t_min, inst_prim, cnt);
+                if (p1 != RT_NONE) {
+                    const GeomS g1 = load_geom(geom, p1);
+                    if (g1.xform == cur_xf) {
+                        changed |= test_prim<LEVEL, COUNT, INST>(sc, p1, g1, pass, ray, h, xo, xd, t_min, inst_prim, cnt);
+                    } else {  // second primitive of a leaf under a different matrix: one-off transform
+                        d3 yo, yd;
+                        apply_xform(sc, g1.xform, ray, yo, yd);
+                        changed |= test_prim<LEVEL, COUNT, INST>(sc, p1, g1, pass, ray, h, yo, yd, t_min, inst_prim, cnt);
                     }
-                    if (__builtin_amdgcn_ballot_w64(any_alive) != 0ull) {  // rare: most tested triangles are nowhere near the rays
-#pragma unroll
-                        for (int r = 0; r < R; ++r) {
-                            double t;
-                            if (la[r] && tri_hit_tail(sa[r], a0, a1, a2, xo[r], xd[r], t_min, ry.h[r].best, t)) { ry.h[r].best = t; ry.h[r].prim = p0; ry.h[r].inst = inst_prim; }
-                            if (lb[r] && tri_hit_tail(sb[r], b0, b1, b2, xo[r], xd[r], t_min, ry.h[r].best, t)) { ry.h[r].best = t; ry.h[r].prim = p1; ry.h[r].inst = inst_prim; }
-                        }
-                        RT_RECONVERGE();
-                    }
-                } else {
-                    test_prim<LEVEL, COUNT, INST, R>(sc, p0, g0, pass, ry, xo, xd, t_min, inst_prim, cnt);
-                    if (rec >= ((RT_STREAM_HDR + RT_STREAM_GEOM + 1u) << 16)) {
-                        const GeomS g1 = window_geom1(w);
-                        if (g1.xform == cur_xf) {
-                            test_prim<LEVEL, COUNT, INST, R>(sc, p1, g1, pass, ry, xo, xd, t_min, inst_prim, cnt);
-                        } else {  // second primitive of a leaf under a different matrix: one-off transform
-                            d3 yo[R], yd[R];
-                            apply_xform<R>(sc, g1.xform, ry, yo, yd);
-                            test_prim<LEVEL, COUNT, INST, R>(sc, p1, g1, pass, ry, yo, yd, t_min, inst_prim, cnt);
-                        }
-                    }
-                    if (COUNT && (rec & RT_NODE_DUP_RIGHT)) {  // reference-order count of the skipped duplicate test
-#pragma unroll
-                        for (int r = 0; r < R; ++r) {
-                            if (g0.kind == RT_PRIM_TRIANGLE) cnt.tri += pass[r] ? 1u : 0u;
-                            else if (g0.kind == RT_PRIM_SPHERE || g0.kind == RT_PRIM_MOVING_SPHERE) cnt.sph += pass[r] ? 1u : 0u;
-                        }
-                    }
-                    RT_RECONVERGE();
                 }
+                if (COUNT && (rec & RT_NODE_DUP_RIGHT)) {  // reference-order count of the skipped duplicate test
+                    if (g0.kind == RT_PRIM_TRIANGLE) cnt.tri += pass ? 1u : 0u;
+                    else if (g0.kind == RT_PRIM_SPHERE || g0.kind == RT_PRIM_MOVING_SPHERE) cnt.sph += pass ? 1u : 0u;
+                }
+                if (MODE == BOX_PLAIN && changed) box_filter_set_best(bf, h.best);
+                RT_RECONVERGE();
             }
         }
         cur_xf = (uint32_t)__builtin_amdgcn_readfirstlane((int)want);
     }
 }
 
-template <int LEVEL, bool COUNT, bool INST, int R>
-RT_DEV void traverse(const SceneDev& sc, uint32_t first, uint32_t end, Rays<R>& ry, const bool (&active)[R], double t_min, uint32_t inst_prim, LaneCount& cnt) {
-    d3 inv[R];
-    bool odd = false;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        inv[r] = mk(1.0 / ry.d[r].x, 1.0 / ry.d[r].y, 1.0 / ry.d[r].z);  // bounding_box.rs:29
-        odd |= active[r] && !(ray_is_plain(ry.o[r], inv[r]) && t_min <= ry.h[r].best);
+template <int LEVEL, bool COUNT, bool INST, class RAYSRC>
+RT_DEV void traverse(const SceneDev& sc, uint32_t first, uint32_t end, const RAYSRC& src, LaneHit& h, bool active, double t_min, uint32_t inst_prim, LaneCount& cnt) {
+    bool odd;
+    {
+        const RayS ray = src.get();
+        const d3 inv = mk(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);  // bounding_box.rs:29
+        odd = active && !(ray_is_plain(ray.o, inv) && t_min <= h.best);
     }
     // the min/max form of the slab test is exact unless a NaN can appear (zero / non-finite direction or origin): decided per wave
     const bool plain = sc.boxes_finite && __builtin_amdgcn_ballot_w64(odd) == 0ull;
-    if (plain) traverse_impl<LEVEL, COUNT, INST, BOX_PLAIN, R>(sc, first, end, ry, inv, active, t_min, inst_prim, cnt);
-    else traverse_impl<LEVEL, COUNT, INST, BOX_LITERAL, R>(sc, first, end, ry, inv, active, t_min, inst_prim, cnt);
+    if (plain) traverse_impl<LEVEL, COUNT, INST, BOX_PLAIN, RAYSRC>(sc, first, end, src, h, active, t_min, inst_prim, cnt);
+    else traverse_impl<LEVEL, COUNT, INST, BOX_LITERAL, RAYSRC>(sc, first, end, src, h, active, t_min, inst_prim, cnt);
 }
 
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES 6  /* waves per SIMD the register allocator must leave room for */
+#endif
 // rays: SoA [7][cap] (ox,oy,oz,dx,dy,dz,time) indexed by path; outputs indexed by path.
-// A wave owns 64*R consecutive queue entries; lane l takes entries l, l+64, ... of that block.
 template <bool COUNT, bool INST>
-__global__ __launch_bounds__(256) void k_trace(SceneDev sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_fixed,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRACE_WAVES))) void k_trace(SceneDev sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_fixed,
                                                const double* __restrict__ rays, uint32_t cap, double t_min, double t_max,
                                                uint32_t* __restrict__ out_prim, uint32_t* __restrict__ out_inst, double* __restrict__ out_t,
                                                unsigned long long* __restrict__ stats) {
-    constexpr int R = RT_RAYS_PER_LANE;
     const uint32_t n = n_ptr ? *n_ptr : n_fixed;
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t wave_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)((tid & ~63u) * R));
+    const uint32_t wave_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid & ~63u));
     if (tid == 0 && stats) atomicAdd(&stats[0], (unsigned long long)n);  // rays traced
     if (wave_first >= n) return;
-    Rays<R> ry;
-    bool valid[R];
-    uint32_t path[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const uint32_t q = wave_first + (tid & 63u) + 64u * r;
-        valid[r] = q < n;
-        path[r] = valid[r] ? (queue ? queue[q] : q) : 0u;
-        ry.o[r] = mk(0, 0, 0); ry.d[r] = mk(1, 1, 1); ry.time[r] = 0.0;
-        if (valid[r]) {
-            ry.o[r] = mk(rays[0 * (size_t)cap + path[r]], rays[1 * (size_t)cap + path[r]], rays[2 * (size_t)cap + path[r]]);
-            ry.d[r] = mk(rays[3 * (size_t)cap + path[r]], rays[4 * (size_t)cap + path[r]], rays[5 * (size_t)cap + path[r]]);
-            ry.time[r] = rays[6 * (size_t)cap + path[r]];
-        }
-        ry.h[r].best = t_max; ry.h[r].prim = RT_NONE; ry.h[r].inst = RT_NONE;
+    const bool valid = tid < n;
+    const uint32_t path = valid ? (queue ? queue[tid] : tid) : 0u;
+    __shared__ double lds_ray[7 * 256];
+    {
+        double* slot = &lds_ray[threadIdx.x];
+        slot[0 * 256] = valid ? rays[0 * (size_t)cap + path] : 0.0; slot[1 * 256] = valid ? rays[1 * (size_t)cap + path] : 0.0;
+        slot[2 * 256] = valid ? rays[2 * (size_t)cap + path] : 0.0; slot[3 * 256] = valid ? rays[3 * (size_t)cap + path] : 1.0;
+        slot[4 * 256] = valid ? rays[4 * (size_t)cap + path] : 1.0; slot[5 * 256] = valid ? rays[5 * (size_t)cap + path] : 1.0;
+        slot[6 * 256] = valid ? rays[6 * (size_t)cap + path] : 0.0;
     }
-    LaneCount cnt; cnt.box = cnt.tri = cnt.sph = 0;
+    RayFromLds src; src.slot = &lds_ray[threadIdx.x];  // each lane reads back only its own slot: no barrier needed
+    LaneHit h; h.best = t_max; h.prim = RT_NONE; h.inst = RT_NONE;
+    LaneCount cnt; cnt.box = cnt.tri = cnt.sph = cnt.bad = 0;
 #ifdef RT_TRACE_DIAG
-    cnt.steps = cnt.leaf_steps = cnt.cyc_wait = cnt.lane_steps = 0; cnt.cyc_total = __builtin_readcyclecounter();
+    cnt.steps = cnt.leaf_steps = cnt.cyc_wait = cnt.lane_steps = cnt.exact_box = cnt.exact_tri = 0; cnt.cyc_total = __builtin_readcyclecounter();
 #endif
-    traverse<0, COUNT, INST, R>(sc, sc.root_off, sc.root_end_off, ry, valid, t_min, RT_NONE, cnt);
+    traverse<0, COUNT, INST, RayFromLds>(sc, sc.root_off, sc.root_end_off, src, h, valid, t_min, RT_NONE, cnt);
 #ifdef RT_TRACE_DIAG
     cnt.cyc_total = __builtin_readcyclecounter() - cnt.cyc_total;
     const uint64_t lane_steps = wave_sum_u64(cnt.lane_steps);
     if (stats && lane_id() == 0) {
         atomicAdd(&stats[9], (unsigned long long)lane_steps);
         atomicMax(&stats[10], (unsigned long long)cnt.steps);
-        if (cnt.steps > 12000) atomicAdd(&stats[11], 1ull);
-        if (cnt.steps > 20000) atomicAdd(&stats[12], 1ull);
+        atomicAdd(&stats[11], (unsigned long long)cnt.exact_box);
+        atomicAdd(&stats[12], (unsigned long long)cnt.exact_tri);
         atomicAdd(&stats[4], (unsigned long long)cnt.steps); atomicAdd(&stats[5], (unsigned long long)cnt.leaf_steps);
         atomicAdd(&stats[6], (unsigned long long)cnt.cyc_wait); atomicAdd(&stats[7], (unsigned long long)cnt.cyc_total); atomicAdd(&stats[8], 1ull);
     }
 #endif
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        if (valid[r]) {
-            out_prim[path[r]] = ry.h[r].prim;
-            if (out_inst) out_inst[path[r]] = ry.h[r].inst;
-            out_t[path[r]] = ry.h[r].prim != RT_NONE ? ry.h[r].best : __builtin_nan("");
-        }
+    if (valid) {
+        out_prim[path] = h.prim;
+        if (out_inst) out_inst[path] = h.inst;
+        out_t[path] = h.prim != RT_NONE ? h.best : __builtin_nan("");
     }
     if (COUNT && stats) {
-        uint64_t b = wave_sum_u64(cnt.box), t = wave_sum_u64(cnt.tri), s = wave_sum_u64(cnt.sph);
-        if (lane_id() == 0) { atomicAdd(&stats[1], (unsigned long long)b); atomicAdd(&stats[2], (unsigned long long)t); atomicAdd(&stats[3], (unsigned long long)s); }
+        uint64_t b = wave_sum_u64(cnt.box), t = wave_sum_u64(cnt.tri), s = wave_sum_u64(cnt.sph), bad = wave_sum_u64(cnt.bad);
+        if (lane_id() == 0) {
+            atomicAdd(&stats[1], (unsigned long long)b); atomicAdd(&stats[2], (unsigned long long)t); atomicAdd(&stats[3], (unsigned long long)s);
+            atomicAdd(&stats[13], (unsigned long long)bad);
+        }
     }
 }
 
@@ -746,6 +912,7 @@ struct rt_scene {
     void* dblob = nullptr;
     uint8_t* d_mat_uses_uv = nullptr;
     uint8_t* d_stream = nullptr;
+    uint32_t* d_node_off = nullptr;
     SceneDev dev{};
     rt_blob_header hdr{};
     std::vector<rt_prim> host_prims;
@@ -825,7 +992,7 @@ static void launch_trace(rt_scene* sc, bool count, const uint32_t* queue, const 
                          double t_max, uint32_t* out_prim, uint32_t* out_inst, double* out_t) {
     hipStream_t st = sc->ctx->stream;
     if (n_bound == 0) return;
-#define RT_LAUNCH_TRACE(C, I) hipLaunchKernelGGL((k_trace<C, I>), grid_for((n_bound + RT_RAYS_PER_LANE - 1) / RT_RAYS_PER_LANE), dim3(256), 0, st, sc->dev, queue, n_ptr, n_bound, rays, sc->ws.cap, t_min, t_max, out_prim, out_inst, out_t, sc->ws.stats)
+#define RT_LAUNCH_TRACE(C, I) hipLaunchKernelGGL((k_trace<C, I>), grid_for(n_bound), dim3(256), 0, st, sc->dev, queue, n_ptr, n_bound, rays, sc->ws.cap, t_min, t_max, out_prim, out_inst, out_t, sc->ws.stats)
     const bool inst = sc->has_instances;  // scenes without BVHNode objects use the kernel variant compiled without the nested walk
 #ifdef RT_TRACE_DIAG
     unsigned long long d0[16];
@@ -843,8 +1010,8 @@ static void launch_trace(rt_scene* sc, bool count, const uint32_t* queue, const 
         for (int k = 0; k < 16; ++k) if (k != 10) d[k] -= d0[k];
         (void)hipMemsetAsync(sc->ws.stats + 10, 0, sizeof(unsigned long long), st);
         const double w = (double)std::max(d[8], 1ull);
-        fprintf(stderr, "[diag] rays %llu waves %llu  steps/wave %.0f  leaf steps/wave %.0f  lane use %.1f%%  cycles/wave %.0f  cycles/step %.0f  wait/step %.0f  max steps %llu  waves>12k %llu  >20k %llu\n",
-                d[0], d[8], d[4] / w, d[5] / w, 100.0 * d[9] / (64.0 * std::max(d[4], 1ull)), d[7] / w, (double)d[7] / std::max(d[4], 1ull), (double)d[6] / std::max(d[4], 1ull), d[10], d[11], d[12]);
+        fprintf(stderr, "[diag] rays %llu waves %llu  steps/wave %.0f  leaf steps/wave %.0f  lane use %.1f%%  cycles/wave %.0f  cycles/step %.0f  wait/step %.0f  max steps %llu  exact box steps/wave %.1f  exact tri steps/wave %.1f\n",
+                d[0], d[8], d[4] / w, d[5] / w, 100.0 * d[9] / (64.0 * std::max(d[4], 1ull)), d[7] / w, (double)d[7] / std::max(d[4], 1ull), (double)d[6] / std::max(d[4], 1ull), d[10], d[11] / w, d[12] / w);
     }
 #endif
 }
@@ -1047,48 +1214,79 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     sc->ctx = ctx; sc->hdr = h;
     sc->host_prims.assign(prims, prims + h.n_prims);
     for (uint32_t i = 0; i < h.n_prims; ++i) sc->has_instances = sc->has_instances || prims[i].kind == RT_PRIM_INSTANCE;
-    // trace stream: pre-order records, header + inline leaf geometry (see k_trace)
-    std::vector<uint64_t> rec_off((size_t)h.n_nodes + 1);
+    // trace stream: pre-order fp32 filter records (see k_trace)
+    if (h.n_nodes >= RT_STREAM_MAX_NODES) { delete sc; return fail(RT_ERR_UNSUPPORTED, "more than 2^24 BVH nodes"); }
+    auto is_tri2 = [&](const rt_node& nd) {  // one triangle, or two under the same transform: leaf with a filter block
+        if (nd.prim0 == RT_NONE || geom[nd.prim0].kind != RT_PRIM_TRIANGLE) return false;
+        return nd.prim1 == RT_NONE || (geom[nd.prim1].kind == RT_PRIM_TRIANGLE && geom[nd.prim0].xform == geom[nd.prim1].xform);
+    };
+    std::vector<uint32_t> rec_off((size_t)h.n_nodes + 1);
     uint64_t stream_bytes = 0;
     for (uint32_t i = 0; i < h.n_nodes; ++i) {
-        rec_off[i] = stream_bytes;
-        stream_bytes += RT_STREAM_HDR + RT_STREAM_GEOM * ((nodes[i].prim0 != RT_NONE) + (nodes[i].prim1 != RT_NONE));
+        rec_off[i] = (uint32_t)stream_bytes;
+        stream_bytes += is_tri2(nodes[i]) ? RT_STREAM_REC_TRI2 : RT_STREAM_REC;
+        if (stream_bytes + RT_STREAM_PAD > 0xFFFFFFF0ull) { delete sc; return fail(RT_ERR_UNSUPPORTED, "trace stream larger than 4 GiB"); }
     }
-    rec_off[h.n_nodes] = stream_bytes;
-    if (stream_bytes + RT_STREAM_PAD > 0xFFFFFFF0ull) { delete sc; return fail(RT_ERR_UNSUPPORTED, "trace stream larger than 4 GiB"); }
+    rec_off[h.n_nodes] = (uint32_t)stream_bytes;
+    auto f32_up = [](double v) {  // smallest float >= v (NaN / overflow: +inf, which disables the filter for that record)
+        if (!(v <= 3.4e38)) return std::numeric_limits<float>::infinity();
+        float f = (float)v;
+        if ((double)f < v) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+        return f;
+    };
     std::vector<uint8_t> stream((size_t)stream_bytes + RT_STREAM_PAD, 0);
+    double box_abs_max = 0.0;
     for (uint32_t i = 0; i < h.n_nodes; ++i) {
+        const rt_node& nd = nodes[i];
         uint8_t* rec = stream.data() + rec_off[i];
-        const uint32_t np = (nodes[i].prim0 != RT_NONE) + (nodes[i].prim1 != RT_NONE);
-        uint32_t fl = nodes[i].flags & (RT_NODE_NO_BOX | RT_NODE_DUP_RIGHT);
-        if (np == 2 && geom[nodes[i].prim0].kind == RT_PRIM_TRIANGLE && geom[nodes[i].prim1].kind == RT_PRIM_TRIANGLE &&
-            geom[nodes[i].prim0].xform == geom[nodes[i].prim1].xform) fl |= RT_STREAM_TRI2;
-        const uint32_t words[4] = {(uint32_t)rec_off[nodes[i].skip], fl | ((RT_STREAM_HDR + RT_STREAM_GEOM * np) << 16), nodes[i].prim0, nodes[i].prim1};
-        double lo[3], hi[3];
-        for (int k = 0; k < 3; ++k) {  // list items have no box in the reference: see traverse_impl
-            const bool nb = (nodes[i].flags & RT_NODE_NO_BOX) != 0;
-            lo[k] = nb ? -std::numeric_limits<double>::infinity() : nodes[i].bmin[k];
-            hi[k] = nb ? std::numeric_limits<double>::infinity() : nodes[i].bmax[k];
+        const bool nb = (nd.flags & RT_NODE_NO_BOX) != 0, tri2 = is_tri2(nd);
+        uint32_t fl = nd.flags & (RT_NODE_NO_BOX | RT_NODE_DUP_RIGHT);
+        if (nd.prim0 != RT_NONE) fl |= RT_STREAM_LEAF;
+        if (tri2) fl |= RT_STREAM_TRI2;
+        float box[6];
+        for (int k = 0; k < 3; ++k) {  // list items have no box in the reference: see the box filter
+            box[2 * k] = nb ? -std::numeric_limits<float>::infinity() : (float)nd.bmin[k];
+            box[2 * k + 1] = nb ? std::numeric_limits<float>::infinity() : (float)nd.bmax[k];
+            if (!nb && std::isfinite(nd.bmin[k]) && std::isfinite(nd.bmax[k])) box_abs_max = std::max(box_abs_max, std::max(std::fabs(nd.bmin[k]), std::fabs(nd.bmax[k])));
         }
-        memcpy(rec, lo, 24); memcpy(rec + 24, hi, 24); memcpy(rec + 48, words, 16);
-        uint32_t slot = 0;
-        for (uint32_t q : {nodes[i].prim0, nodes[i].prim1}) {
-            if (q == RT_NONE) continue;
-            rt_geom g = geom[q];
-            if (g.kind == RT_PRIM_INSTANCE) { g.d[0] = (double)rec_off[prims[q].index]; g.d[1] = (double)rec_off[prims[q].sub_end]; }
-            memcpy(rec + RT_STREAM_HDR + RT_STREAM_GEOM * slot++, &g, sizeof g);
+        const uint32_t words[2] = {rec_off[nd.skip], fl | (((tri2 ? RT_STREAM_REC_TRI2 : RT_STREAM_REC) / 16u) << 4) | (i << 8)};
+        memcpy(rec, box, 24); memcpy(rec + 24, words, 8);
+        if (!tri2) continue;
+        float blk[28] = {};
+        const uint32_t xf = geom[nd.prim0].xform;
+        memcpy(&blk[0], &xf, 4);
+        for (int t = 0; t < 2; ++t) {  // pairs (A, B): e2, ml = v0 x e2, -n = -(e1 x e2), then the error weights (see the triangle filter)
+            const rt_geom& g = geom[(t == 0 || nd.prim1 == RT_NONE) ? nd.prim0 : nd.prim1];  // a single triangle fills both halves
+            const double* v0 = g.d; const double* e1 = g.d + 3; const double* e2 = g.d + 6;
+            const double ml[3] = {v0[1] * e2[2] - v0[2] * e2[1], v0[2] * e2[0] - v0[0] * e2[2], v0[0] * e2[1] - v0[1] * e2[0]};
+            const double nn[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+            auto n1 = [](const double* v) { return std::fabs(v[0]) + std::fabs(v[1]) + std::fabs(v[2]); };
+            auto ninf = [](const double* v) { return std::max(std::max(std::fabs(v[0]), std::fabs(v[1])), std::fabs(v[2])); };
+            for (int k = 0; k < 3; ++k) {
+                blk[2 + 2 * k + t] = (float)e2[k];
+                blk[2 + 2 * (3 + k) + t] = (float)ml[k];
+                blk[2 + 2 * (6 + k) + t] = (float)-nn[k];
+            }
+            blk[2 + 2 * 9 + t] = f32_up(0x1p-20 * ninf(e2));
+            blk[2 + 2 * 10 + t] = f32_up(0x1p-20 * n1(ml) + 0x1p-46 * ninf(v0) * n1(e2));
+            blk[2 + 2 * 11 + t] = f32_up((1.0 + 0x1p-19) * (0x1p-20 * n1(nn) + 0x1p-46 * n1(e1) * n1(e2)));
         }
+        memcpy(rec + RT_STREAM_REC, blk, sizeof blk);
     }
+    static_assert(RT_STREAM_REC + 28 * 4 == RT_STREAM_REC_TRI2, "TRI2 record layout");
     hipError_t e = hipMalloc(&sc->dblob, nbytes);
     if (e == hipSuccess) e = hipMalloc((void**)&sc->d_mat_uses_uv, uses_uv.size());
     if (e == hipSuccess) e = hipMalloc((void**)&sc->d_stream, stream.size());
     if (e == hipSuccess) e = hipMemcpy(sc->d_stream, stream.data(), stream.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&sc->d_node_off, rec_off.size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpy(sc->d_node_off, rec_off.data(), rec_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(sc->dblob, blob, nbytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(sc->d_mat_uses_uv, uses_uv.data(), uses_uv.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         if (sc->dblob) (void)hipFree(sc->dblob);
         if (sc->d_mat_uses_uv) (void)hipFree(sc->d_mat_uses_uv);
         if (sc->d_stream) (void)hipFree(sc->d_stream);
+        if (sc->d_node_off) (void)hipFree(sc->d_node_off);
         delete sc;
         return fail(e == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, hipGetErrorString(e));
     }
@@ -1100,7 +1298,8 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     v.materials = (const rt_material*)(d + h.off_materials); v.textures = (const rt_texture*)(d + h.off_textures);
     v.texels = d + h.off_texels; v.lights = (const rt_light*)(d + h.off_lights);
     v.mat_uses_uv = sc->d_mat_uses_uv;
-    v.stream = sc->d_stream; v.root_off = (uint32_t)rec_off[h.root_node]; v.root_end_off = (uint32_t)rec_off[h.root_end];
+    v.stream = sc->d_stream; v.root_off = rec_off[h.root_node]; v.root_end_off = rec_off[h.root_end];
+    v.node_off = sc->d_node_off; v.box_abs_max = box_abs_max;
     v.n_nodes = h.n_nodes; v.boxes_finite = boxes_finite ? 1u : 0u;
     v.camera = h.camera; v.n_lights = h.n_lights; v.root_node = h.root_node; v.root_end = h.root_end; v.background = h.background;
     {   // ray-sorting grid: mean +- 2.5 sigma of the scene-level leaf-box centres (robust against a 1000-unit ground sphere
@@ -1137,6 +1336,7 @@ int rt_scene_destroy(rt_scene* sc) {
     (void)hipFree(sc->dblob);
     (void)hipFree(sc->d_mat_uses_uv);
     (void)hipFree(sc->d_stream);
+    (void)hipFree(sc->d_node_off);
     delete sc;
     return RT_OK;
 }
@@ -1157,7 +1357,7 @@ int rt_trace_closest_device(rt_scene* sc, uint32_t n, const double* rays_dev, do
 int rt_trace_closest(rt_scene* sc, uint32_t n, const double* rays, double t_min, double t_max, uint32_t* prim_id, uint32_t* inst_id, double* t,
                      uint64_t* counters) {
     if (!sc || (n && (!rays || !prim_id || !t))) return fail(RT_ERR_BAD_ARG, "rt_trace_closest: null argument");
-    if (n == 0) { if (counters) counters[0] = counters[1] = counters[2] = 0; return RT_OK; }
+    if (n == 0) { if (counters) counters[0] = counters[1] = counters[2] = counters[3] = 0; return RT_OK; }
     HIP_OK(hipSetDevice(sc->ctx->device));
     int rc = ws_ensure(sc, n, sc->ws.depth > 0 ? sc->ws.depth : 1);
     if (rc != RT_OK) return rc;
@@ -1167,11 +1367,11 @@ int rt_trace_closest(rt_scene* sc, uint32_t n, const double* rays, double t_min,
     for (uint32_t i = 0; i < n; ++i)
         for (int c = 0; c < 7; ++c) soa[(size_t)c * ws.cap + i] = rays[(size_t)i * 7 + c];
     HIP_OK(hipMemcpyAsync(ws.pb.rays, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemsetAsync(ws.stats, 0, 4 * sizeof(unsigned long long), st));
+    HIP_OK(hipMemsetAsync(ws.stats, 0, 16 * sizeof(unsigned long long), st));
     launch_trace(sc, counters != nullptr, nullptr, nullptr, n, ws.pb.rays, t_min, t_max, ws.pb.hit_prim, ws.pb.hit_inst, ws.pb.hit_t);
     HIP_OK(hipGetLastError());
     std::vector<uint32_t> hp(n), hi(n);
-    unsigned long long st4[4];
+    unsigned long long st4[16];
     HIP_OK(hipMemcpyAsync(hp.data(), ws.pb.hit_prim, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(hi.data(), ws.pb.hit_inst, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(t, ws.pb.hit_t, n * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1183,7 +1383,7 @@ int rt_trace_closest(rt_scene* sc, uint32_t n, const double* rays, double t_min,
         prim_id[i] = p.object_id;
         if (inst_id) inst_id[i] = hi[i] != RT_NONE ? sc->host_prims[hi[i]].inst_id : p.inst_id;
     }
-    if (counters) { counters[0] = st4[1]; counters[1] = st4[2]; counters[2] = st4[3]; }
+    if (counters) { counters[0] = st4[1]; counters[1] = st4[2]; counters[2] = st4[3]; counters[3] = st4[13]; }
     return RT_OK;
 }
 
@@ -1259,7 +1459,7 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
     hipStream_t st = sc->ctx->stream;
     const bool count_tests = (p->flags & RT_RENDER_COUNT_TESTS) != 0;
     const bool sort_rays = (p->flags & RT_RENDER_NO_SORT) == 0 && sc->sortable;
-    HIP_OK(hipMemsetAsync(ws.stats, 0, 4 * sizeof(unsigned long long), st));
+    HIP_OK(hipMemsetAsync(ws.stats, 0, 16 * sizeof(unsigned long long), st));
     EventTimer tm(st, stats != nullptr);
     hipEvent_t e0, e1;
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
@@ -1276,7 +1476,7 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
         launches += 1;
     }
     HIP_OK(hipEventRecord(e1, st));
-    unsigned long long st4[4];
+    unsigned long long st4[16];
     HIP_OK(hipMemcpyAsync(st4, ws.stats, sizeof st4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     HIP_OK(hipGetLastError());
@@ -1288,7 +1488,7 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
         stats->rays = st4[0]; stats->box_tests = st4[1]; stats->tri_tests = st4[2]; stats->sphere_tests = st4[3];
         stats->paths = (uint64_t)npix * spp; stats->launches = launches;
         stats->ms_total = ms; stats->ms_trace = by_cat[CAT_TRACE]; stats->ms_shade = by_cat[CAT_SHADE]; stats->ms_other = by_cat[CAT_OTHER];
-        stats->trace_launches = n_by_cat[CAT_TRACE];
+        stats->trace_launches = n_by_cat[CAT_TRACE]; stats->filter_violations = st4[13];
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return RT_OK;

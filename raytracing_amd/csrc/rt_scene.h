@@ -26,7 +26,9 @@ struct SceneDev {
     const uint8_t* texels;
     const rt_light* lights;
     const uint8_t* mat_uses_uv;
-    const uint8_t* stream;  // trace stream (rt_device.hip): node headers with their leaf geometry inline
+    const uint8_t* stream;  // trace stream (rt_device.hip): fp32 filter records in pre-order
+    const uint32_t* node_off;  // [n_nodes + 1] byte offset of each node's record in `stream`
+    double box_abs_max;        // max |coordinate| over the finite boxes (box filter error bound)
     uint32_t root_off, root_end_off;  // byte range of the scene-level records in `stream`
     rt_camera camera;
     uint32_t n_lights, root_node, root_end, background;

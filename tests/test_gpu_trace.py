@@ -46,7 +46,11 @@ def test_primary_hits_bit_exact(gpu_ctx, name, legacy_bvh, w, h):
     _assert_same_hits(g, o)
     assert (o[0] != rt.NONE).sum() > 0
     # same traversal order => same number of box / triangle / sphere tests as the reference recursion
-    assert list(map(int, g[3])) == list(map(int, o[3][:3])), (g[3], o[3])
+    assert list(map(int, g[3][:3])) == list(map(int, o[3][:3])), (g[3], o[3])
+    # the counting kernel decides everything with the exact f64 tests and checks every fp32 filter decision against them
+    assert int(g[3][3]) == 0, f"{int(g[3][3])} filter decisions contradicted by the exact test"
+    # the production kernel (filters first, exact tests for the undecided lanes) must give the same bits
+    _assert_same_hits(gs.trace_closest(rays, 0.001, 100000.0), o)
     gs.close()
 
 
@@ -63,7 +67,11 @@ def test_incoherent_rays_bit_exact(gpu_ctx, name, legacy_bvh):
     rays[:, 6] = rng.uniform(0, 1, n)
     rays[::97, 4] = 0.0   # exact zero direction components: +-inf / NaN slab paths (bounding_box.rs:29)
     rays[::89, 3] = 0.0
-    _assert_same_hits(gs.trace_closest(rays, 0.001, 10000.0), osc.trace_closest(rays, 0.001, 10000.0))
+    o = osc.trace_closest(rays, 0.001, 10000.0)
+    _assert_same_hits(gs.trace_closest(rays, 0.001, 10000.0), o)
+    g = gs.trace_closest(rays, 0.001, 10000.0, counters=True)
+    _assert_same_hits(g, o)
+    assert list(map(int, g[3][:3])) == list(map(int, o[3][:3])) and int(g[3][3]) == 0, (g[3], o[3])
     gs.close()
 
 
@@ -181,7 +189,7 @@ def test_gpu_matches_committed_golden_vectors(gpu_ctx):
         prim, inst, t, cnt = gs.trace_closest(rays, 0.001, 100000.0, counters=True)
         assert np.array_equal(prim, g[f"{name}_prim"]) and np.array_equal(inst, g[f"{name}_inst"])
         assert np.array_equal(t.view(np.uint64), g[f"{name}_t"].view(np.uint64))
-        assert list(map(int, cnt)) == list(map(int, g[f"{name}_cnt"][:3]))
+        assert list(map(int, cnt[:3])) == list(map(int, g[f"{name}_cnt"][:3])) and int(cnt[3]) == 0
         picks = g[f"{name}_picks"]
         for integ in range(4):
             got = gs.sample_radiance(w, h, picks[:, 1] * w + picks[:, 0], picks[:, 2], 5, integ, 77)
