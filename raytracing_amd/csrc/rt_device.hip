@@ -64,10 +64,25 @@ RT_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdg
 // ------------------------------------------------------------------------------------------------
 // k_trace: Scene::hit (scene.rs:31-38 -> bvh.rs:91-106 / hittable.rs:41-53) for a queue of rays
 // ------------------------------------------------------------------------------------------------
-struct LaneHit {
-    double best;         // current t_max (bvh.rs:98-101)
-    uint32_t prim, inst; // indices into the prims table
+// The running closest hit of a lane lives in LDS, not in registers: only the exact paths read or write it, and as
+// loop-carried registers these values cost the hot path a handful of copies per leaf (and four VGPRs).
+template <class T> using lptr = __attribute__((address_space(3))) T*;
+template <class T> struct LdsCell {
+    lptr<volatile T> p;
+    RT_DEV operator T() const { return *p; }
+    RT_DEV LdsCell& operator=(T v) { *p = v; return *this; }
 };
+template <class T> struct RegCell {
+    T v;
+    RT_DEV operator T() const { return v; }
+    RT_DEV RegCell& operator=(T x) { v = x; return *this; }
+};
+template <template <class> class CELL> struct LaneHitT {
+    CELL<double> best;           // current t_max (bvh.rs:98-101)
+    CELL<uint32_t> prim, inst;   // indices into the prims table
+};
+typedef LaneHitT<LdsCell> LaneHit;      // triangle scenes
+typedef LaneHitT<RegCell> LaneHitRegs;  // scenes whose leaf steps are exact tests anyway (k_trace<.., REGS = true>)
 struct LaneCount {
     uint32_t box, tri, sph;
     uint32_t bad;  // COUNT variant only: filter decisions contradicted by the exact test (must stay 0)
@@ -95,6 +110,7 @@ RT_DEV GeomS load_geom(cptr<rt_geom> geom, uint32_t p) {
 //     header, 32 B:  fp32 box as (min, max) pairs per axis | skip_off | flags(4) + record bytes/16 (4) + node index (24)
 //     + for a leaf of one triangle (block repeats it) or two under one transform (RT_STREAM_TRI2), 112 B:
 //       xform id | pad | 12 fp32 (A, B) pairs: e2.xyz, ml.xyz = v0 x e2, -n.xyz = -(e1 x e2), E2', ML', N'' (error weights)
+//     + for a leaf of one or two spheres under one transform (RT_STREAM_SPH2), 80 B: xform id | count | (centre, radius) f64 x 2
 // A traversal step loads one window of the stream (two s_load_dwordx16 + one dwordx2 issued back to back,
 // ONE wait): the header, the triangle block if any, and the line after it, which holds the records the
 // walk visits next when it continues sequentially.  The loads are inline asm because the compiler sinks
@@ -105,8 +121,13 @@ RT_DEV GeomS load_geom(cptr<rt_geom> geom, uint32_t p) {
 // tables (nodes[node index], geom[prim]), which is the reference's arithmetic operation for operation.
 // So results never depend on the filters -- only on their error bounds being valid, which the COUNT
 // variant of the kernel re-checks against the exact test for every decision (LaneCount::bad).
-#define RT_STREAM_TRI2 4u      /* header flag (stream only): leaf of one triangle, or two under the same transform, with filter block */
-#define RT_STREAM_LEAF 8u      /* header flag (stream only): record has primitives */
+/* bits 2-3 of the header flags (stream only): what the record holds */
+#define RT_STREAM_KIND 12u
+#define RT_STREAM_INNER 0u
+#define RT_STREAM_TRI2 4u      /* leaf of one triangle, or two under the same transform, with fp32 filter block */
+#define RT_STREAM_LEAF 8u      /* any other leaf: exact tests on the blob's own tables */
+#define RT_STREAM_SPH2 12u     /* leaf of one or two spheres under the same transform, f64 geometry inline */
+#define RT_STREAM_REC_SPH2 112u
 #define RT_STREAM_REC 32u
 #define RT_STREAM_REC_TRI2 144u
 #define RT_STREAM_PAD 384u     /* readable bytes past the last record: the window over-reads */
@@ -130,6 +151,7 @@ template <int K> RT_DEV uint32_t wword(const Window& w) {
     else if constexpr (K < 32) return w.b[K - 16];
     else return w.c[K - 32];
 }
+RT_DEV double sdbl(uint32_t lo, uint32_t hi) { return __builtin_bit_cast(double, ((uint64_t)hi << 32) | (uint64_t)lo); }
 template <int K> RT_DEV uint64_t wpair(const Window& w) { return ((uint64_t)wword<K + 1>(w) << 32) | (uint64_t)wword<K>(w); }  // dwords K, K+1 as one SGPR pair
 template <int J> RT_DEV uint64_t tri_pair(const Window& w) { return wpair<10 + 2 * J>(w); }
 
@@ -264,17 +286,15 @@ RT_DEV void tri_filter(const TriFilter& f, const Window& w, lanemask& rejA, lane
 struct RayS { d3 o, d; double time; };  // ray as handed to this traversal level
 // Where a traversal level gets its f64 ray from.  Only the fp32 filter state is live across the hot loop; the exact
 // paths (a few percent of the steps) fetch the f64 ray again instead of holding 14 VGPRs per lane for it:
-// the top level parks it in LDS (14 KB per block; the asm keeps the reads inside the rare blocks), an instance
+// the top level parks it in LDS (14 KB per block; volatile reads stay inside the rare blocks), an instance
 // level keeps the transformed ray it was handed in registers.
 struct RayFromLds {
-    const double* slot;  // &lds[threadIdx.x]; component c at slot[c * 256]
+    lptr<volatile double> slot;  // &lds[threadIdx.x]; component c at slot[c * 256]
     RT_DEV RayS get() const {
-        const double* p = slot;
-        asm volatile("" : "+v"(p));
         RayS r;
-        r.o = mk(p[0 * 256], p[1 * 256], p[2 * 256]);
-        r.d = mk(p[3 * 256], p[4 * 256], p[5 * 256]);
-        r.time = p[6 * 256];
+        r.o = mk(slot[0 * 256], slot[1 * 256], slot[2 * 256]);
+        r.d = mk(slot[3 * 256], slot[4 * 256], slot[5 * 256]);
+        r.time = slot[6 * 256];
         return r;
     }
 };
@@ -283,8 +303,8 @@ struct RayInRegisters {
     RT_DEV RayS get() const { return r; }
 };
 
-template <int LEVEL, bool COUNT, bool INST, class RAYSRC>
-RT_DEV void traverse(const SceneDev& sc, uint32_t first, uint32_t end, const RAYSRC& src, LaneHit& h, bool active, double t_min, uint32_t inst_prim, LaneCount& cnt);
+template <int LEVEL, bool COUNT, bool INST, class RAYSRC, class HIT>
+RT_DEV void traverse(const SceneDev& sc, uint32_t first, uint32_t end, const RAYSRC& src, HIT& h, bool active, double t_min, uint32_t inst_prim, LaneCount& cnt);
 
 RT_DEV bool ray_is_plain(d3 o, d3 inv) {  // box_axis_fast precondition: no NaN can appear in (b - o) * inv
     return isfinite(o.x) && isfinite(o.y) && isfinite(o.z) && isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z) && inv.x != 0.0 && inv.y != 0.0 && inv.z != 0.0;
@@ -305,8 +325,8 @@ RT_DEV void apply_xform(const SceneDev& sc, uint32_t xform, const RayS& ray, d3&
 
 // One primitive against the wave's rays (exact f64); (xo, xd) is the ray already in the primitive's space.
 // Returns true if the lane's closest hit changed.
-template <int LEVEL, bool COUNT, bool INST>
-RT_DEV bool test_prim(const SceneDev& sc, uint32_t p, const GeomS& g, bool pass, const RayS& ray, LaneHit& h, d3 xo, d3 xd,
+template <int LEVEL, bool COUNT, bool INST, class HIT>
+RT_DEV bool test_prim(const SceneDev& sc, uint32_t p, const GeomS& g, bool pass, const RayS& ray, HIT& h, d3 xo, d3 xd,
                       double t_min, uint32_t inst_prim, LaneCount& cnt) {
     bool changed = false;
     if (g.kind == RT_PRIM_TRIANGLE) {
@@ -331,8 +351,8 @@ RT_DEV bool test_prim(const SceneDev& sc, uint32_t p, const GeomS& g, bool pass,
         RayInRegisters sub; sub.r.o = xo; sub.r.d = xd; sub.r.time = ray.time;
         const double before = h.best;
         cptr<uint32_t> node_off = as_const(sc.node_off);
-        traverse<1, COUNT, INST, RayInRegisters>(sc, node_off[(uint32_t)g.d[0]], node_off[(uint32_t)g.d[1]], sub, h, pass, t_min, p, cnt);
-        changed = h.best != before;
+        traverse<1, COUNT, INST, RayInRegisters, HIT>(sc, node_off[(uint32_t)g.d[0]], node_off[(uint32_t)g.d[1]], sub, h, pass, t_min, p, cnt);
+        changed = (double)h.best != before;
     }
     return changed;
 }
@@ -365,8 +385,8 @@ RT_DEV bool box_exact(cptr<rt_node> nodes, uint32_t node, d3 o, d3 d, double t_m
            box_axis(nd.bmin[2], nd.bmax[2], o.z, inv.z, t_min, best);
 }
 
-template <int LEVEL, bool COUNT, bool INST, int MODE, class RAYSRC>
-RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, uint32_t end, const RAYSRC& src, LaneHit& h, bool active, double t_min,
+template <int LEVEL, bool COUNT, bool INST, int MODE, class RAYSRC, class HIT>
+RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, uint32_t end, const RAYSRC& src, HIT& h, bool active, double t_min,
                           uint32_t inst_prim, LaneCount& cnt) {
     uint32_t wait = active ? first : 0xFFFFFFFFu;
     uint32_t off = first, cur_xf = RT_NONE;
@@ -397,7 +417,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, uint32_t end, cons
             const uint32_t skip = wword<6>(w), rec = wword<7>(w);
             const uint32_t node = rec >> 8;
 #ifdef RT_TRACE_DIAG
-            cnt.cyc_wait += __builtin_readcyclecounter() - c0; cnt.steps += 1; cnt.leaf_steps += (rec & RT_STREAM_LEAF) ? 1u : 0u;
+            cnt.cyc_wait += __builtin_readcyclecounter() - c0; cnt.steps += 1; cnt.leaf_steps += (rec & RT_STREAM_KIND) ? 1u : 0u;
 #endif
             const lanemask m_act = mask_reached(off, wait);
 #ifdef RT_TRACE_DIAG
@@ -426,9 +446,36 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, uint32_t end, cons
             wait = mask_select(wait, skip, m_act & ~m_pass);
             if (m_pass == 0ull) {
                 off = skip;
-            } else if (!(rec & RT_STREAM_LEAF)) {
+            } else if ((rec & RT_STREAM_KIND) == RT_STREAM_INNER) {
                 off += RT_STREAM_REC;
-            } else if (rec & RT_STREAM_TRI2) {  // the common leaf: one or two triangles under one transform
+            } else if ((rec & RT_STREAM_KIND) == RT_STREAM_SPH2) {  // one or two spheres: exact f64 test (shape.rs:93-121) on inline geometry
+                if (wword<8>(w) != cur_xf) {
+                    if (COUNT && !(rec & RT_NODE_NO_BOX)) cnt.box -= mask_lane(m_pass) ? 1u : 0u;
+                    want = wword<8>(w);
+                    break;
+                }
+                off += RT_STREAM_REC_SPH2;
+                const uint32_t nsph = wword<9>(w);
+                const RayS ray = src.get();
+                d3 xo, xd;
+                apply_xform(sc, cur_xf, ray, xo, xd);
+                const bool pass = mask_lane(m_pass);
+                if (COUNT) cnt.sph += pass ? (nsph + ((rec & RT_NODE_DUP_RIGHT) ? 1u : 0u)) : 0u;
+                double t;
+                bool changed = false;
+                if (pass && sphere_hit(mk(sdbl(wword<10>(w), wword<11>(w)), sdbl(wword<12>(w), wword<13>(w)), sdbl(wword<14>(w), wword<15>(w))),
+                                       sdbl(wword<16>(w), wword<17>(w)), xo, xd, t_min, h.best, t)) {
+                    h.best = t; h.prim = nodes[node].prim0; h.inst = inst_prim; changed = true;
+                }
+                if (nsph > 1u) {
+                    if (pass && sphere_hit(mk(sdbl(wword<18>(w), wword<19>(w)), sdbl(wword<20>(w), wword<21>(w)), sdbl(wword<22>(w), wword<23>(w))),
+                                           sdbl(wword<24>(w), wword<25>(w)), xo, xd, t_min, h.best, t)) {
+                        h.best = t; h.prim = nodes[node].prim1; h.inst = inst_prim; changed = true;
+                    }
+                }
+                if (MODE == BOX_PLAIN && changed) box_filter_set_best(bf, h.best);
+                RT_RECONVERGE();
+            } else if ((rec & RT_STREAM_KIND) == RT_STREAM_TRI2) {  // the common leaf: one or two triangles under one transform
                 if (wword<8>(w) != cur_xf) {  // re-enter at this record with the rays in the leaf's space
                     if (COUNT && !(rec & RT_NODE_NO_BOX)) cnt.box -= mask_lane(m_pass) ? 1u : 0u;  // the repeated box test must not count twice
                     want = wword<8>(w);
@@ -485,15 +532,15 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, uint32_t end, cons
                 const RayS ray = src.get();
                 d3 xo, xd;
                 apply_xform(sc, cur_xf, ray, xo, xd);
-                bool changed = test_prim<LEVEL, COUNT, INST>(sc, p0, g0, pass, ray, h, xo, xd, t_min, inst_prim, cnt);
+                bool changed = test_prim<LEVEL, COUNT, INST, HIT>(sc, p0, g0, pass, ray, h, xo, xd, t_min, inst_prim, cnt);
                 if (p1 != RT_NONE) {
                     const GeomS g1 = load_geom(geom, p1);
                     if (g1.xform == cur_xf) {
-                        changed |= test_prim<LEVEL, COUNT, INST>(sc, p1, g1, pass, ray, h, xo, xd, t_min, inst_prim, cnt);
+                        changed |= test_prim<LEVEL, COUNT, INST, HIT>(sc, p1, g1, pass, ray, h, xo, xd, t_min, inst_prim, cnt);
                     } else {  // second primitive of a leaf under a different matrix: one-off transform
                         d3 yo, yd;
                         apply_xform(sc, g1.xform, ray, yo, yd);
-                        changed |= test_prim<LEVEL, COUNT, INST>(sc, p1, g1, pass, ray, h, yo, yd, t_min, inst_prim, cnt);
+                        changed |= test_prim<LEVEL, COUNT, INST, HIT>(sc, p1, g1, pass, ray, h, yo, yd, t_min, inst_prim, cnt);
                     }
                 }
                 if (COUNT && (rec & RT_NODE_DUP_RIGHT)) {  // reference-order count of the skipped duplicate test
@@ -508,8 +555,8 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, uint32_t end, cons
     }
 }
 
-template <int LEVEL, bool COUNT, bool INST, class RAYSRC>
-RT_DEV void traverse(const SceneDev& sc, uint32_t first, uint32_t end, const RAYSRC& src, LaneHit& h, bool active, double t_min, uint32_t inst_prim, LaneCount& cnt) {
+template <int LEVEL, bool COUNT, bool INST, class RAYSRC, class HIT>
+RT_DEV void traverse(const SceneDev& sc, uint32_t first, uint32_t end, const RAYSRC& src, HIT& h, bool active, double t_min, uint32_t inst_prim, LaneCount& cnt) {
     bool odd;
     {
         const RayS ray = src.get();
@@ -518,16 +565,21 @@ RT_DEV void traverse(const SceneDev& sc, uint32_t first, uint32_t end, const RAY
     }
     // the min/max form of the slab test is exact unless a NaN can appear (zero / non-finite direction or origin): decided per wave
     const bool plain = sc.boxes_finite && __builtin_amdgcn_ballot_w64(odd) == 0ull;
-    if (plain) traverse_impl<LEVEL, COUNT, INST, BOX_PLAIN, RAYSRC>(sc, first, end, src, h, active, t_min, inst_prim, cnt);
-    else traverse_impl<LEVEL, COUNT, INST, BOX_LITERAL, RAYSRC>(sc, first, end, src, h, active, t_min, inst_prim, cnt);
+    if (plain) traverse_impl<LEVEL, COUNT, INST, BOX_PLAIN, RAYSRC, HIT>(sc, first, end, src, h, active, t_min, inst_prim, cnt);
+    else traverse_impl<LEVEL, COUNT, INST, BOX_LITERAL, RAYSRC, HIT>(sc, first, end, src, h, active, t_min, inst_prim, cnt);
 }
 
 #ifndef RT_TRACE_WAVES
 #define RT_TRACE_WAVES 6  /* waves per SIMD the register allocator must leave room for */
 #endif
+#ifndef RT_TRACE_WAVES_REGS
+#define RT_TRACE_WAVES_REGS 3
+#endif
 // rays: SoA [7][cap] (ox,oy,oz,dx,dy,dz,time) indexed by path; outputs indexed by path.
-template <bool COUNT, bool INST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRACE_WAVES))) void k_trace(SceneDev sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_fixed,
+// REGS: keep the f64 ray in registers instead of LDS -- for scenes whose leaves are mostly not triangles, where
+// (almost) every leaf step runs an exact f64 test and would read the ray back from LDS each time.
+template <bool COUNT, bool INST, bool REGS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : REGS ? RT_TRACE_WAVES_REGS : RT_TRACE_WAVES))) void k_trace(SceneDev sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_fixed,
                                                const double* __restrict__ rays, uint32_t cap, double t_min, double t_max,
                                                uint32_t* __restrict__ out_prim, uint32_t* __restrict__ out_inst, double* __restrict__ out_t,
                                                unsigned long long* __restrict__ stats) {
@@ -539,6 +591,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRACE_WA
     const bool valid = tid < n;
     const uint32_t path = valid ? (queue ? queue[tid] : tid) : 0u;
     __shared__ double lds_ray[7 * 256];
+    __shared__ double lds_best[256];
+    __shared__ uint32_t lds_prim[256], lds_inst[256];
     {
         double* slot = &lds_ray[threadIdx.x];
         slot[0 * 256] = valid ? rays[0 * (size_t)cap + path] : 0.0; slot[1 * 256] = valid ? rays[1 * (size_t)cap + path] : 0.0;
@@ -546,13 +600,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRACE_WA
         slot[4 * 256] = valid ? rays[4 * (size_t)cap + path] : 1.0; slot[5 * 256] = valid ? rays[5 * (size_t)cap + path] : 1.0;
         slot[6 * 256] = valid ? rays[6 * (size_t)cap + path] : 0.0;
     }
-    RayFromLds src; src.slot = &lds_ray[threadIdx.x];  // each lane reads back only its own slot: no barrier needed
-    LaneHit h; h.best = t_max; h.prim = RT_NONE; h.inst = RT_NONE;
+    RayFromLds src; src.slot = (lptr<volatile double>)&lds_ray[threadIdx.x];  // each lane reads back only its own slot: no barrier needed
+    RayInRegisters src_regs;
+    if (REGS) src_regs.r = src.get();
+    LaneHit h;
+    h.best.p = (lptr<volatile double>)&lds_best[threadIdx.x]; h.prim.p = (lptr<volatile uint32_t>)&lds_prim[threadIdx.x]; h.inst.p = (lptr<volatile uint32_t>)&lds_inst[threadIdx.x];
+    h.best = t_max; h.prim = RT_NONE; h.inst = RT_NONE;
     LaneCount cnt; cnt.box = cnt.tri = cnt.sph = cnt.bad = 0;
 #ifdef RT_TRACE_DIAG
     cnt.steps = cnt.leaf_steps = cnt.cyc_wait = cnt.lane_steps = cnt.exact_box = cnt.exact_tri = 0; cnt.cyc_total = __builtin_readcyclecounter();
 #endif
-    traverse<0, COUNT, INST, RayFromLds>(sc, sc.root_off, sc.root_end_off, src, h, valid, t_min, RT_NONE, cnt);
+    if (REGS) {
+        LaneHitRegs hr; hr.best = t_max; hr.prim = RT_NONE; hr.inst = RT_NONE;
+        traverse<0, COUNT, INST, RayInRegisters, LaneHitRegs>(sc, sc.root_off, sc.root_end_off, src_regs, hr, valid, t_min, RT_NONE, cnt);
+        h.best = (double)hr.best; h.prim = (uint32_t)hr.prim; h.inst = (uint32_t)hr.inst;
+    } else {
+        traverse<0, COUNT, INST, RayFromLds, LaneHit>(sc, sc.root_off, sc.root_end_off, src, h, valid, t_min, RT_NONE, cnt);
+    }
 #ifdef RT_TRACE_DIAG
     cnt.cyc_total = __builtin_readcyclecounter() - cnt.cyc_total;
     const uint64_t lane_steps = wave_sum_u64(cnt.lane_steps);
@@ -566,9 +630,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRACE_WA
     }
 #endif
     if (valid) {
-        out_prim[path] = h.prim;
-        if (out_inst) out_inst[path] = h.inst;
-        out_t[path] = h.prim != RT_NONE ? h.best : __builtin_nan("");
+        const uint32_t hp = h.prim;
+        out_prim[path] = hp;
+        if (out_inst) out_inst[path] = (uint32_t)h.inst;
+        out_t[path] = hp != RT_NONE ? (double)h.best : __builtin_nan("");
     }
     if (COUNT && stats) {
         uint64_t b = wave_sum_u64(cnt.box), t = wave_sum_u64(cnt.tri), s = wave_sum_u64(cnt.sph), bad = wave_sum_u64(cnt.bad);
@@ -917,6 +982,7 @@ struct rt_scene {
     rt_blob_header hdr{};
     std::vector<rt_prim> host_prims;
     bool has_instances = false;
+    bool reg_ray = false;   // most leaves are not triangles: k_trace variant with the f64 ray in registers
     bool sortable = false;  // scene has a finite box to quantise ray origins against
     Workspace ws;
 };
@@ -992,7 +1058,8 @@ static void launch_trace(rt_scene* sc, bool count, const uint32_t* queue, const 
                          double t_max, uint32_t* out_prim, uint32_t* out_inst, double* out_t) {
     hipStream_t st = sc->ctx->stream;
     if (n_bound == 0) return;
-#define RT_LAUNCH_TRACE(C, I) hipLaunchKernelGGL((k_trace<C, I>), grid_for(n_bound), dim3(256), 0, st, sc->dev, queue, n_ptr, n_bound, rays, sc->ws.cap, t_min, t_max, out_prim, out_inst, out_t, sc->ws.stats)
+#define RT_LAUNCH_TRACE_R(C, I, R) hipLaunchKernelGGL((k_trace<C, I, R>), grid_for(n_bound), dim3(256), 0, st, sc->dev, queue, n_ptr, n_bound, rays, sc->ws.cap, t_min, t_max, out_prim, out_inst, out_t, sc->ws.stats)
+#define RT_LAUNCH_TRACE(C, I) do { if (sc->reg_ray) RT_LAUNCH_TRACE_R(C, I, true); else RT_LAUNCH_TRACE_R(C, I, false); } while (0)
     const bool inst = sc->has_instances;  // scenes without BVHNode objects use the kernel variant compiled without the nested walk
 #ifdef RT_TRACE_DIAG
     unsigned long long d0[16];
@@ -1001,6 +1068,7 @@ static void launch_trace(rt_scene* sc, bool count, const uint32_t* queue, const 
 #endif
     if (count) { if (inst) RT_LAUNCH_TRACE(true, true); else RT_LAUNCH_TRACE(true, false); }
     else { if (inst) RT_LAUNCH_TRACE(false, true); else RT_LAUNCH_TRACE(false, false); }
+#undef RT_LAUNCH_TRACE_R
 #undef RT_LAUNCH_TRACE
 #ifdef RT_TRACE_DIAG
     {
@@ -1220,11 +1288,15 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
         if (nd.prim0 == RT_NONE || geom[nd.prim0].kind != RT_PRIM_TRIANGLE) return false;
         return nd.prim1 == RT_NONE || (geom[nd.prim1].kind == RT_PRIM_TRIANGLE && geom[nd.prim0].xform == geom[nd.prim1].xform);
     };
+    auto is_sph2 = [&](const rt_node& nd) {  // one sphere, or two under the same transform
+        if (nd.prim0 == RT_NONE || geom[nd.prim0].kind != RT_PRIM_SPHERE) return false;
+        return nd.prim1 == RT_NONE || (geom[nd.prim1].kind == RT_PRIM_SPHERE && geom[nd.prim0].xform == geom[nd.prim1].xform);
+    };
     std::vector<uint32_t> rec_off((size_t)h.n_nodes + 1);
     uint64_t stream_bytes = 0;
     for (uint32_t i = 0; i < h.n_nodes; ++i) {
         rec_off[i] = (uint32_t)stream_bytes;
-        stream_bytes += is_tri2(nodes[i]) ? RT_STREAM_REC_TRI2 : RT_STREAM_REC;
+        stream_bytes += is_tri2(nodes[i]) ? RT_STREAM_REC_TRI2 : is_sph2(nodes[i]) ? RT_STREAM_REC_SPH2 : RT_STREAM_REC;
         if (stream_bytes + RT_STREAM_PAD > 0xFFFFFFF0ull) { delete sc; return fail(RT_ERR_UNSUPPORTED, "trace stream larger than 4 GiB"); }
     }
     rec_off[h.n_nodes] = (uint32_t)stream_bytes;
@@ -1239,18 +1311,24 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     for (uint32_t i = 0; i < h.n_nodes; ++i) {
         const rt_node& nd = nodes[i];
         uint8_t* rec = stream.data() + rec_off[i];
-        const bool nb = (nd.flags & RT_NODE_NO_BOX) != 0, tri2 = is_tri2(nd);
+        const bool nb = (nd.flags & RT_NODE_NO_BOX) != 0, tri2 = is_tri2(nd), sph2 = is_sph2(nd);
         uint32_t fl = nd.flags & (RT_NODE_NO_BOX | RT_NODE_DUP_RIGHT);
-        if (nd.prim0 != RT_NONE) fl |= RT_STREAM_LEAF;
-        if (tri2) fl |= RT_STREAM_TRI2;
+        fl |= tri2 ? RT_STREAM_TRI2 : sph2 ? RT_STREAM_SPH2 : nd.prim0 != RT_NONE ? RT_STREAM_LEAF : RT_STREAM_INNER;
+        const uint32_t rec_bytes = tri2 ? RT_STREAM_REC_TRI2 : sph2 ? RT_STREAM_REC_SPH2 : RT_STREAM_REC;
         float box[6];
         for (int k = 0; k < 3; ++k) {  // list items have no box in the reference: see the box filter
             box[2 * k] = nb ? -std::numeric_limits<float>::infinity() : (float)nd.bmin[k];
             box[2 * k + 1] = nb ? std::numeric_limits<float>::infinity() : (float)nd.bmax[k];
             if (!nb && std::isfinite(nd.bmin[k]) && std::isfinite(nd.bmax[k])) box_abs_max = std::max(box_abs_max, std::max(std::fabs(nd.bmin[k]), std::fabs(nd.bmax[k])));
         }
-        const uint32_t words[2] = {rec_off[nd.skip], fl | (((tri2 ? RT_STREAM_REC_TRI2 : RT_STREAM_REC) / 16u) << 4) | (i << 8)};
+        const uint32_t words[2] = {rec_off[nd.skip], fl | ((rec_bytes / 16u) << 4) | (i << 8)};
         memcpy(rec, box, 24); memcpy(rec + 24, words, 8);
+        if (sph2) {
+            const uint32_t head[2] = {geom[nd.prim0].xform, nd.prim1 != RT_NONE ? 2u : 1u};
+            memcpy(rec + RT_STREAM_REC, head, 8);
+            memcpy(rec + RT_STREAM_REC + 8, geom[nd.prim0].d, 32);  // centre xyz, radius
+            if (nd.prim1 != RT_NONE) memcpy(rec + RT_STREAM_REC + 40, geom[nd.prim1].d, 32);
+        }
         if (!tri2) continue;
         float blk[28] = {};
         const uint32_t xf = geom[nd.prim0].xform;
@@ -1274,6 +1352,11 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
         memcpy(rec + RT_STREAM_REC, blk, sizeof blk);
     }
     static_assert(RT_STREAM_REC + 28 * 4 == RT_STREAM_REC_TRI2, "TRI2 record layout");
+    {
+        uint64_t n_leaf = 0, n_tri_leaf = 0;
+        for (uint32_t i = 0; i < h.n_nodes; ++i) { n_leaf += nodes[i].prim0 != RT_NONE; n_tri_leaf += is_tri2(nodes[i]); }
+        sc->reg_ray = 2 * n_tri_leaf < n_leaf;
+    }
     hipError_t e = hipMalloc(&sc->dblob, nbytes);
     if (e == hipSuccess) e = hipMalloc((void**)&sc->d_mat_uses_uv, uses_uv.size());
     if (e == hipSuccess) e = hipMalloc((void**)&sc->d_stream, stream.size());
