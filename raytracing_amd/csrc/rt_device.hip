@@ -111,6 +111,8 @@ RT_DEV GeomS load_geom(cptr<rt_geom> geom, uint32_t p) {
 //     + for a leaf of one triangle (block repeats it) or two under one transform (RT_STREAM_TRI2), 112 B:
 //       xform id | pad | 12 fp32 (A, B) pairs: e2.xyz, ml.xyz = v0 x e2, -n.xyz = -(e1 x e2), E2', ML', N'' (error weights)
 //     + for a leaf of one or two spheres under one transform (RT_STREAM_SPH2), 80 B: xform id | count | (centre, radius) f64 x 2
+// Every range (the scene-level array, each instance sub-array) is closed by an END record -- a list-item header that
+// every ray passes -- so the walk needs no bounds test: skip links to the end of a range land on it.
 // A traversal step loads one window of the stream (two s_load_dwordx16 + one dwordx2 issued back to back,
 // ONE wait): the header, the triangle block if any, and the line after it, which holds the records the
 // walk visits next when it continues sequentially.  The loads are inline asm because the compiler sinks
@@ -131,7 +133,8 @@ RT_DEV GeomS load_geom(cptr<rt_geom> geom, uint32_t p) {
 #define RT_STREAM_REC 32u
 #define RT_STREAM_REC_TRI2 144u
 #define RT_STREAM_PAD 384u     /* readable bytes past the last record: the window over-reads */
-#define RT_STREAM_MAX_NODES (1u << 24)
+#define RT_STREAM_END_NODE 0xFFFFFFu  /* node field of the END record that closes every range (scene array, each instance sub-array) */
+#define RT_STREAM_MAX_NODES RT_STREAM_END_NODE
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -304,7 +307,7 @@ struct RayInRegisters {
 };
 
 template <int LEVEL, bool COUNT, bool INST, class RAYSRC, class HIT>
-RT_DEV void traverse(const SceneDev& sc, uint32_t first, uint32_t end, const RAYSRC& src, HIT& h, bool active, double t_min, uint32_t inst_prim, LaneCount& cnt);
+RT_DEV void traverse(const SceneDev& sc, uint32_t first, const RAYSRC& src, HIT& h, bool active, double t_min, uint32_t inst_prim, LaneCount& cnt);
 
 RT_DEV bool ray_is_plain(d3 o, d3 inv) {  // box_axis_fast precondition: no NaN can appear in (b - o) * inv
     return isfinite(o.x) && isfinite(o.y) && isfinite(o.z) && isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z) && inv.x != 0.0 && inv.y != 0.0 && inv.z != 0.0;
@@ -351,7 +354,7 @@ RT_DEV bool test_prim(const SceneDev& sc, uint32_t p, const GeomS& g, bool pass,
         RayInRegisters sub; sub.r.o = xo; sub.r.d = xd; sub.r.time = ray.time;
         const double before = h.best;
         cptr<uint32_t> node_off = as_const(sc.node_off);
-        traverse<1, COUNT, INST, RayInRegisters, HIT>(sc, node_off[(uint32_t)g.d[0]], node_off[(uint32_t)g.d[1]], sub, h, pass, t_min, p, cnt);
+        traverse<1, COUNT, INST, RayInRegisters, HIT>(sc, node_off[(uint32_t)g.d[0]], sub, h, pass, t_min, p, cnt);
         changed = (double)h.best != before;
     }
     return changed;
@@ -373,11 +376,12 @@ RT_DEV bool test_prim(const SceneDev& sc, uint32_t p, const GeomS& g, bool pass,
 // (An octant-uniform form -- near/far planes picked by scalar selects -- measured slower: the scalar unit is
 // as loaded as the vector unit in this loop.)
 enum { BOX_LITERAL = 0, BOX_PLAIN = 1 };
+#define RT_WALK_DONE 0xFFFFFFFEu  /* `want` value that ends the walk (never a transform id: RT_NONE is 0xFFFFFFFF, ids are < n_xforms) */
 template <bool PLAIN>
-RT_DEV bool box_exact(cptr<rt_node> nodes, uint32_t node, d3 o, d3 d, double t_min, double best) {
-    const RT_CONST rt_node& nd = nodes[node];
+RT_DEV bool box_exact(cptr<rt_node> nodes, uint32_t rec, d3 o, d3 d, double t_min, double best) {
+    if (rec & RT_NODE_NO_BOX) return true;  // hittable.rs:41-53: list items are tested without a box (also the END record, which has no node)
+    const RT_CONST rt_node& nd = nodes[rec >> 8];
     const d3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);  // bounding_box.rs:29 (re-derived: not worth three live register pairs)
-    if (nd.flags & RT_NODE_NO_BOX) return true;  // hittable.rs:41-53: list items are tested without a box
     if (PLAIN)
         return box_axis_fast(nd.bmin[0], nd.bmax[0], o.x, inv.x, t_min, best) & box_axis_fast(nd.bmin[1], nd.bmax[1], o.y, inv.y, t_min, best) &
                box_axis_fast(nd.bmin[2], nd.bmax[2], o.z, inv.z, t_min, best);
@@ -386,7 +390,7 @@ RT_DEV bool box_exact(cptr<rt_node> nodes, uint32_t node, d3 o, d3 d, double t_m
 }
 
 template <int LEVEL, bool COUNT, bool INST, int MODE, class RAYSRC, class HIT>
-RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, uint32_t end, const RAYSRC& src, HIT& h, bool active, double t_min,
+RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src, HIT& h, bool active, double t_min,
                           uint32_t inst_prim, LaneCount& cnt) {
     uint32_t wait = active ? first : 0xFFFFFFFFu;
     uint32_t off = first, cur_xf = RT_NONE;
@@ -398,7 +402,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, uint32_t end, cons
         const RayS ray = src.get();
         box_filter_init(bf, ray.o, mk(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z), t_min, h.best, sc.box_abs_max);
     }
-    while (off < end) {
+    for (;;) {  // one round per transform the walk has to enter; the END record of the range leaves both loops
         TriFilter tf;
         {
             const RayS ray = src.get();
@@ -407,11 +411,12 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, uint32_t end, cons
             tri_filter_init(tf, xo, xd);
         }
         uint32_t want = cur_xf;
-        while (off < end) {
+        for (;;) {
             Window w;
 #ifdef RT_TRACE_DIAG
             const uint64_t c0 = __builtin_readcyclecounter();
 #endif
+            if (INST) off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);  // the nested walk makes the compiler class the (wave-uniform) cursor divergent
             window_issue(w, base, off);
             window_wait(w);
             const uint32_t skip = wword<6>(w), rec = wword<7>(w);
@@ -432,7 +437,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, uint32_t end, cons
                 if (COUNT || (m_act & ~(cp | cf)) != 0ull) {  // rare: a plane value within the error bound of best / t_min
                     const RayS ray = src.get();
                     const bool act = mask_lane(m_act);
-                    const bool ex = act & box_exact<true>(nodes, node, ray.o, ray.d, t_min, h.best);
+                    const bool ex = act & box_exact<true>(nodes, rec, ray.o, ray.d, t_min, h.best);
                     if (COUNT) cnt.bad += (act & ((mask_lane(cp) & !ex) | (mask_lane(cf) & ex))) ? 1u : 0u;
                     m_pass = __builtin_amdgcn_ballot_w64(ex);
 #ifdef RT_TRACE_DIAG
@@ -441,7 +446,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, uint32_t end, cons
                 }
             } else {
                 const RayS ray = src.get();
-                m_pass = __builtin_amdgcn_ballot_w64(mask_lane(m_act) & box_exact<false>(nodes, node, ray.o, ray.d, t_min, h.best));
+                m_pass = __builtin_amdgcn_ballot_w64(mask_lane(m_act) & box_exact<false>(nodes, rec, ray.o, ray.d, t_min, h.best));
             }
             wait = mask_select(wait, skip, m_act & ~m_pass);
             if (m_pass == 0ull) {
@@ -520,6 +525,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, uint32_t end, cons
                     RT_RECONVERGE();
                 }
             } else {  // any other leaf: exact tests on the blob's tables
+                if (node == RT_STREAM_END_NODE) { want = RT_WALK_DONE; break; }  // END record: every ray still waiting has arrived at the end of the range
                 const uint32_t p0 = nodes[node].prim0, p1 = nodes[node].prim1;
                 const GeomS g0 = load_geom(geom, p0);
                 const bool pass = mask_lane(m_pass);
@@ -551,12 +557,13 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, uint32_t end, cons
                 RT_RECONVERGE();
             }
         }
+        if (want == RT_WALK_DONE) break;
         cur_xf = (uint32_t)__builtin_amdgcn_readfirstlane((int)want);
     }
 }
 
 template <int LEVEL, bool COUNT, bool INST, class RAYSRC, class HIT>
-RT_DEV void traverse(const SceneDev& sc, uint32_t first, uint32_t end, const RAYSRC& src, HIT& h, bool active, double t_min, uint32_t inst_prim, LaneCount& cnt) {
+RT_DEV void traverse(const SceneDev& sc, uint32_t first, const RAYSRC& src, HIT& h, bool active, double t_min, uint32_t inst_prim, LaneCount& cnt) {
     bool odd;
     {
         const RayS ray = src.get();
@@ -565,8 +572,8 @@ RT_DEV void traverse(const SceneDev& sc, uint32_t first, uint32_t end, const RAY
     }
     // the min/max form of the slab test is exact unless a NaN can appear (zero / non-finite direction or origin): decided per wave
     const bool plain = sc.boxes_finite && __builtin_amdgcn_ballot_w64(odd) == 0ull;
-    if (plain) traverse_impl<LEVEL, COUNT, INST, BOX_PLAIN, RAYSRC, HIT>(sc, first, end, src, h, active, t_min, inst_prim, cnt);
-    else traverse_impl<LEVEL, COUNT, INST, BOX_LITERAL, RAYSRC, HIT>(sc, first, end, src, h, active, t_min, inst_prim, cnt);
+    if (plain) traverse_impl<LEVEL, COUNT, INST, BOX_PLAIN, RAYSRC, HIT>(sc, first, src, h, active, t_min, inst_prim, cnt);
+    else traverse_impl<LEVEL, COUNT, INST, BOX_LITERAL, RAYSRC, HIT>(sc, first, src, h, active, t_min, inst_prim, cnt);
 }
 
 #ifndef RT_TRACE_WAVES
@@ -612,10 +619,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : 
 #endif
     if (REGS) {
         LaneHitRegs hr; hr.best = t_max; hr.prim = RT_NONE; hr.inst = RT_NONE;
-        traverse<0, COUNT, INST, RayInRegisters, LaneHitRegs>(sc, sc.root_off, sc.root_end_off, src_regs, hr, valid, t_min, RT_NONE, cnt);
+        traverse<0, COUNT, INST, RayInRegisters, LaneHitRegs>(sc, sc.root_off, src_regs, hr, valid, t_min, RT_NONE, cnt);
         h.best = (double)hr.best; h.prim = (uint32_t)hr.prim; h.inst = (uint32_t)hr.inst;
     } else {
-        traverse<0, COUNT, INST, RayFromLds, LaneHit>(sc, sc.root_off, sc.root_end_off, src, h, valid, t_min, RT_NONE, cnt);
+        traverse<0, COUNT, INST, RayFromLds, LaneHit>(sc, sc.root_off, src, h, valid, t_min, RT_NONE, cnt);
     }
 #ifdef RT_TRACE_DIAG
     cnt.cyc_total = __builtin_readcyclecounter() - cnt.cyc_total;
@@ -1292,14 +1299,27 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
         if (nd.prim0 == RT_NONE || geom[nd.prim0].kind != RT_PRIM_SPHERE) return false;
         return nd.prim1 == RT_NONE || (geom[nd.prim1].kind == RT_PRIM_SPHERE && geom[nd.prim0].xform == geom[nd.prim1].xform);
     };
-    std::vector<uint32_t> rec_off((size_t)h.n_nodes + 1);
+    // ranges: the scene-level array and every instance sub-array (validated above: disjoint, links stay inside);
+    // range_end[i] = end index of the range node i belongs to, ends_here[e] = some range ends before node e
+    std::vector<uint32_t> range_end((size_t)h.n_nodes, h.n_nodes);
+    std::vector<uint8_t> ends_here((size_t)h.n_nodes + 1, 0);
+    for (uint32_t k = h.root_node; k < h.root_end; ++k) range_end[k] = h.root_end;
+    ends_here[h.root_end] = 1;
+    for (uint32_t i = 0; i < h.n_prims; ++i)
+        if (prims[i].kind == RT_PRIM_INSTANCE) {
+            for (uint32_t k = prims[i].index; k < prims[i].sub_end; ++k) range_end[k] = prims[i].sub_end;
+            ends_here[prims[i].sub_end] = 1;
+        }
+    std::vector<uint32_t> rec_off((size_t)h.n_nodes + 1), end_off((size_t)h.n_nodes + 1, 0);
     uint64_t stream_bytes = 0;
-    for (uint32_t i = 0; i < h.n_nodes; ++i) {
+    for (uint32_t i = 0; i <= h.n_nodes; ++i) {
+        if (ends_here[i]) { end_off[i] = (uint32_t)stream_bytes; stream_bytes += RT_STREAM_REC; }  // END record of the range(s) ending here
         rec_off[i] = (uint32_t)stream_bytes;
-        stream_bytes += is_tri2(nodes[i]) ? RT_STREAM_REC_TRI2 : is_sph2(nodes[i]) ? RT_STREAM_REC_SPH2 : RT_STREAM_REC;
+        if (i < h.n_nodes) stream_bytes += is_tri2(nodes[i]) ? RT_STREAM_REC_TRI2 : is_sph2(nodes[i]) ? RT_STREAM_REC_SPH2 : RT_STREAM_REC;
         if (stream_bytes + RT_STREAM_PAD > 0xFFFFFFF0ull) { delete sc; return fail(RT_ERR_UNSUPPORTED, "trace stream larger than 4 GiB"); }
     }
-    rec_off[h.n_nodes] = (uint32_t)stream_bytes;
+    // a link to the end of the node's own range lands on that range's END record
+    auto link_off = [&](uint32_t from, uint32_t to) { return to == range_end[from] ? end_off[to] : rec_off[to]; };
     auto f32_up = [](double v) {  // smallest float >= v (NaN / overflow: +inf, which disables the filter for that record)
         if (!(v <= 3.4e38)) return std::numeric_limits<float>::infinity();
         float f = (float)v;
@@ -1307,6 +1327,13 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
         return f;
     };
     std::vector<uint8_t> stream((size_t)stream_bytes + RT_STREAM_PAD, 0);
+    for (uint32_t e = 0; e <= h.n_nodes; ++e) {
+        if (!ends_here[e]) continue;
+        const float inf = std::numeric_limits<float>::infinity();
+        const float box[6] = {-inf, inf, -inf, inf, -inf, inf};
+        const uint32_t words[2] = {end_off[e], RT_NODE_NO_BOX | RT_STREAM_LEAF | ((RT_STREAM_REC / 16u) << 4) | (RT_STREAM_END_NODE << 8)};
+        memcpy(stream.data() + end_off[e], box, 24); memcpy(stream.data() + end_off[e] + 24, words, 8);
+    }
     double box_abs_max = 0.0;
     for (uint32_t i = 0; i < h.n_nodes; ++i) {
         const rt_node& nd = nodes[i];
@@ -1321,7 +1348,7 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
             box[2 * k + 1] = nb ? std::numeric_limits<float>::infinity() : (float)nd.bmax[k];
             if (!nb && std::isfinite(nd.bmin[k]) && std::isfinite(nd.bmax[k])) box_abs_max = std::max(box_abs_max, std::max(std::fabs(nd.bmin[k]), std::fabs(nd.bmax[k])));
         }
-        const uint32_t words[2] = {rec_off[nd.skip], fl | ((rec_bytes / 16u) << 4) | (i << 8)};
+        const uint32_t words[2] = {link_off(i, nd.skip), fl | ((rec_bytes / 16u) << 4) | (i << 8)};
         memcpy(rec, box, 24); memcpy(rec + 24, words, 8);
         if (sph2) {
             const uint32_t head[2] = {geom[nd.prim0].xform, nd.prim1 != RT_NONE ? 2u : 1u};
@@ -1381,7 +1408,7 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     v.materials = (const rt_material*)(d + h.off_materials); v.textures = (const rt_texture*)(d + h.off_textures);
     v.texels = d + h.off_texels; v.lights = (const rt_light*)(d + h.off_lights);
     v.mat_uses_uv = sc->d_mat_uses_uv;
-    v.stream = sc->d_stream; v.root_off = rec_off[h.root_node]; v.root_end_off = rec_off[h.root_end];
+    v.stream = sc->d_stream; v.root_off = h.root_node == h.root_end ? end_off[h.root_end] : rec_off[h.root_node];
     v.node_off = sc->d_node_off; v.box_abs_max = box_abs_max;
     v.n_nodes = h.n_nodes; v.boxes_finite = boxes_finite ? 1u : 0u;
     v.camera = h.camera; v.n_lights = h.n_lights; v.root_node = h.root_node; v.root_end = h.root_end; v.background = h.background;

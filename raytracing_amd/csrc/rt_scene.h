@@ -29,7 +29,7 @@ struct SceneDev {
     const uint8_t* stream;  // trace stream (rt_device.hip): fp32 filter records in pre-order
     const uint32_t* node_off;  // [n_nodes + 1] byte offset of each node's record in `stream`
     double box_abs_max;        // max |coordinate| over the finite boxes (box filter error bound)
-    uint32_t root_off, root_end_off;  // byte range of the scene-level records in `stream`
+    uint32_t root_off;  // first scene-level record in `stream` (the range is closed by an END record)
     rt_camera camera;
     uint32_t n_lights, root_node, root_end, background;
     uint32_t n_nodes, boxes_finite;
