@@ -1,0 +1,164 @@
+"""GPU parity under stress of the fp32 filters of k_trace.
+
+The production kernel classifies box and triangle tests in fp32 and hands undecided lanes to the exact f64
+tests; results may only depend on the error bounds being valid.  These cases aim rays AT the decision
+boundaries (triangle edges and vertices, box faces and corners, coplanar rays), scale the scene to the
+ends of the fp32 range where the bounds are disabled, and use rays whose magnitudes make the margins
+huge.  Every case must be bit-exact against the oracle, from the production kernel and from the counting
+kernel, and the counting kernel (which evaluates filter AND exact test for every decision) must report
+zero contradicted decisions."""
+import numpy as np
+import pytest
+
+import oracle_ffi as orc
+import raytracing_amd as rt
+from scene_text import SceneText, scale, translate
+
+pytestmark = pytest.mark.gpu
+
+
+def _soup(seed, n_tri, extent, wrap=None, bvh_seed=4):
+    """Random triangle soup (one mesh, BVH over the triangles, optionally every triangle under one transform)."""
+    rng = np.random.default_rng(seed)
+    s = SceneText(bvh_seed=bvh_seed)
+    m = s.lambertian_rgb(.5, .5, .5)
+    centres = rng.uniform(-extent, extent, (n_tri, 3))
+    verts, faces = [], []
+    for k in range(n_tri):
+        for _ in range(3):
+            verts.append(tuple(centres[k] + rng.normal(size=3) * extent * 0.08))
+        faces.append((3 * k, 3 * k + 1, 3 * k + 2))
+    me = s.mesh(verts, [(0, 0, 1)] * len(verts), [(0, 0)] * len(verts), faces, m)
+    xf = s.xform(wrap) if wrap is not None else None
+    ids = []
+    for k in range(n_tri):
+        t = s.triangle(me, k)
+        ids.append(s.transformed(xf, t) if xf is not None else t)
+    return s.finish(ids, build_bvh=True), np.array(verts).reshape(n_tri, 3, 3), rng
+
+
+def _check(gpu_ctx, text, rays, t_min=0.001, t_max=1e5):
+    osc = orc.OracleScene(text)
+    gs = gpu_ctx.upload(rt.HostScene.from_description(text))
+    o = osc.trace_closest(rays, t_min, t_max)
+    g = gs.trace_closest(rays, t_min, t_max)
+    c = gs.trace_closest(rays, t_min, t_max, counters=True)
+    gs.close()
+    for r in (g, c):
+        assert np.array_equal(r[0], o[0]), f"{(r[0] != o[0]).sum()} primitive ids differ"
+        assert np.array_equal(r[2].view(np.uint64), o[2].view(np.uint64)), "t differs in bits"
+    assert list(map(int, c[3][:3])) == list(map(int, o[3][:3])), (c[3], o[3])
+    assert int(c[3][3]) == 0, f"{int(c[3][3])} filter decisions contradicted by the exact test"
+    return o
+
+
+def _rays_at(points, origins, jitter_ulps=0, rng=None):
+    d = points - origins
+    if jitter_ulps:
+        d = d * (1.0 + rng.integers(-jitter_ulps, jitter_ulps + 1, d.shape) * 2.0 ** -52)
+    rays = np.zeros((len(points), 7))
+    rays[:, :3] = origins
+    rays[:, 3:6] = d
+    return rays
+
+
+def test_rays_at_triangle_edges_vertices_and_planes(gpu_ctx):
+    text, tris, rng = _soup(1, 300, 4.0)
+    n = 4000
+    k = rng.integers(0, len(tris), n)
+    a, b = rng.uniform(0, 1, n), rng.uniform(0, 1, n)
+    kind = rng.integers(0, 4, n)
+    # barycentric targets: on edge u = 0, on edge u + v = 1, at a vertex, strictly inside
+    u = np.where(kind == 0, 0.0, np.where(kind == 1, a, np.where(kind == 2, 1.0, a * (1 - b))))
+    v = np.where(kind == 0, a, np.where(kind == 1, 1 - a, np.where(kind == 2, 0.0, b * (1 - a * (1 - b)))))
+    p = tris[k, 0] + u[:, None] * (tris[k, 1] - tris[k, 0]) + v[:, None] * (tris[k, 2] - tris[k, 0])
+    org = rng.uniform(-9, 9, (n, 3))
+    hit = _check(gpu_ctx, text, _rays_at(p, org, jitter_ulps=3, rng=rng))
+    assert (hit[0] != rt.NONE).sum() > n // 4
+    # rays lying (almost) in the plane of a triangle: det ~ 0, every quantity of the u test is tiny
+    e1, e2 = tris[k, 1] - tris[k, 0], tris[k, 2] - tris[k, 0]
+    org = tris[k, 0] + 5.0 * e1 - 3.0 * e2
+    tgt = tris[k, 0] + a[:, None] * e1 + b[:, None] * e2
+    _check(gpu_ctx, text, _rays_at(tgt, org, jitter_ulps=2, rng=rng))
+
+
+def test_rays_at_box_faces_and_corners(gpu_ctx):
+    # every BVH box is the union of triangle boxes, so triangle-box corners and face points are box faces
+    text, tris, rng = _soup(2, 200, 3.0)
+    lo, hi = tris.min(axis=1), tris.max(axis=1)
+    n = 4000
+    k = rng.integers(0, len(tris), n)
+    pick = rng.integers(0, 2, (n, 3))
+    corner = np.where(pick == 0, lo[k], hi[k])
+    face = corner.copy()
+    ax = rng.integers(0, 3, n)
+    other = (ax + 1) % 3
+    face[np.arange(n), other] = rng.uniform(lo[k, other], hi[k, other])
+    org = rng.uniform(-8, 8, (n, 3))
+    # axis-parallel origins put exact zeros into the direction for a part of the rays (literal f64 path)
+    org[::7, 0] = corner[::7, 0]
+    _check(gpu_ctx, text, _rays_at(corner, org))
+    _check(gpu_ctx, text, _rays_at(face, org, jitter_ulps=1, rng=rng))
+    # shadow-ray style windows: t_max exactly at / just around a box entry distance
+    rays = _rays_at(corner, org)
+    _check(gpu_ctx, text, rays, t_min=0.001, t_max=1.0)
+    _check(gpu_ctx, text, rays, t_min=1.0, t_max=1.0 + 2.0 ** -30)
+
+
+@pytest.mark.parametrize("s", [1e-25, 1e-12, 1e9, 1e28, 1e33])
+def test_scene_scales_up_to_where_the_filters_switch_off(gpu_ctx, s):
+    # 1e28 .. 1e33: products leave the fp32 range, the filters must answer "unknown", never "certain"
+    text, tris, rng = _soup(3, 120, 2.0 * s)
+    n = 1500
+    k = rng.integers(0, len(tris), n)
+    p = tris[k].mean(axis=1) + rng.normal(size=(n, 3)) * 0.05 * s
+    org = rng.uniform(-6, 6, (n, 3)) * s
+    o = _check(gpu_ctx, text, _rays_at(p, org), t_min=0.001, t_max=1e300)
+    if s >= 1.0:  # below, |det| < EPSILON for every triangle: the reference itself hits nothing (mesh.rs:59-61)
+        assert (o[0] != rt.NONE).sum() > 0
+
+
+def test_extreme_ray_magnitudes_and_far_origins(gpu_ctx):
+    text, tris, rng = _soup(4, 200, 3.0, wrap=translate(5.0, -2.0, 1.0))
+    n = 3000
+    k = rng.integers(0, len(tris), n)
+    p = tris[k].mean(axis=1) + np.array([5.0, -2.0, 1.0]) + rng.normal(size=(n, 3)) * 0.1
+    org = rng.uniform(-7, 7, (n, 3))
+    rays = _rays_at(p, org)
+    mag = 10.0 ** rng.uniform(-36, 36, n)   # |d| from 1e-36 to 1e36: 1/d leaves the filter's range on both sides
+    rays[:, 3:6] *= mag[:, None]
+    _check(gpu_ctx, text, rays, t_min=0.0, t_max=1e300)
+    far = _rays_at(p, org * 1e7)            # origins 1e7 away: margins of order 1, nearly everything is "unknown"
+    _check(gpu_ctx, text, far)
+    mixed = rays.copy()
+    mixed[::5, 3] = 0.0; mixed[::11, 4] = -0.0; mixed[::13, 5] = 0.0   # zero components inside otherwise plain waves
+    _check(gpu_ctx, text, mixed, t_min=0.0, t_max=1e300)
+
+
+def test_single_triangle_leaves_and_mixed_leaves(gpu_ctx):
+    # odd object counts give 1-object leaves (duplicate right child, bvh.rs:37-43); spheres mixed in give
+    # sphere leaves, triangle+sphere leaves (generic exact path) and leaves whose halves use different matrices
+    rng = np.random.default_rng(9)
+    s = SceneText(bvh_seed=2)
+    m = s.lambertian_rgb(.5, .5, .5)
+    verts, faces = [], []
+    for k in range(37):
+        c = rng.uniform(-3, 3, 3)
+        for _ in range(3):
+            verts.append(tuple(c + rng.normal(size=3) * 0.4))
+        faces.append((3 * k, 3 * k + 1, 3 * k + 2))
+    me = s.mesh(verts, [(0, 0, 1)] * len(verts), [(0, 0)] * len(verts), faces, m)
+    xa, xb = s.xform(translate(0.5, 0, 0)), s.xform(scale(1.5, 0.75, 1.25))
+    ids = []
+    for k in range(37):
+        t = s.triangle(me, k)
+        ids.append(t if k % 3 == 0 else s.transformed(xa if k % 3 == 1 else xb, t))
+    for k in range(20):
+        sp = s.sphere(tuple(rng.uniform(-3, 3, 3)), float(rng.uniform(0.1, 0.6)), m)
+        ids.append(sp if k % 2 else s.transformed(xa, sp))
+    ids.append(s.aarect(-1, 1, -1, 1, 0.5, m))
+    text = s.finish(ids, build_bvh=True)
+    n = 4000
+    org = rng.uniform(-6, 6, (n, 3))
+    tgt = rng.uniform(-3, 3, (n, 3))
+    _check(gpu_ctx, text, _rays_at(tgt, org))
