@@ -178,7 +178,10 @@ RT_CMP_F32(mask_le, "le") RT_CMP_F32(mask_ge, "ge") RT_CMP_F32(mask_gt, "gt") RT
 RT_DEV lanemask mask_ge_const(float a, float s) { lanemask m; asm("v_cmp_ge_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "s"(s)); return m; }
 RT_DEV lanemask mask_neg(float a) { lanemask m; asm("v_cmp_gt_f32_e64 %0, 0, %1" : "=s"(m) : "v"(a)); return m; }
 RT_DEV lanemask mask_reached(uint32_t off, uint32_t wait) { lanemask m; asm("v_cmp_ge_u32_e64 %0, %1, %2" : "=s"(m) : "s"(off), "v"(wait)); return m; }
-RT_DEV uint32_t mask_select(uint32_t a, uint32_t b, lanemask m) { uint32_t r; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m)); return r; }  // m ? b : a
+RT_DEV lanemask mask_uniform(lanemask m) {  // a no-op for a mask the compiler already holds in SGPRs; the variants with the nested walk sometimes class it divergent
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
+}
+RT_DEV uint32_t mask_select(uint32_t a, uint32_t b, lanemask m) { uint32_t r; m = mask_uniform(m); asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m)); return r; }  // m ? b : a
 RT_DEV bool mask_lane(lanemask m) { return mask_select(0u, 1u, m) != 0u; }  // this lane's bit (exact paths only)
 
 // double -> float with the result strictly on the stated side (RN conversion errs by <= 2^-24 |x|)
@@ -230,10 +233,22 @@ RT_DEV void box_filter(const BoxFilter& f, const Window& w, lanemask& cp, lanema
     PK_FMA_BB(tx, wpair<0>(w), f.inv_xy, 0, f.invz_cx, 1);
     PK_FMA_BB(ty, wpair<2>(w), f.inv_xy, 1, f.c_yz, 0);
     PK_FMA_BB(tz, wpair<4>(w), f.invz_cx, 0, f.c_yz, 1);
-    const float nearmax = vmax3_f32(vmin_f32(tx.x, tx.y), vmin_f32(ty.x, ty.y), vmin_f32(tz.x, tz.y));
-    const float farmin = vmin3_f32(vmax_f32(tx.x, tx.y), vmax_f32(ty.x, ty.y), vmax_f32(tz.x, tz.y));
-    cp = mask_le(nearmax, f.hiP) & mask_ge(farmin, f.loP);
-    cf = mask_gt(nearmax, f.hiF) | mask_lt(farmin, f.loF);
+    // one asm block: separate asm statements each cost a conservative hazard s_nop, and the scalar unit is the busy one
+    float n0, n1, n2, f0, f1, f2;
+    lanemask m0, m1, m2, m3;
+    asm("v_min_f32 %[n0], %[ax], %[bx]\n\tv_max_f32 %[f0], %[ax], %[bx]\n\t"
+        "v_min_f32 %[n1], %[ay], %[by]\n\tv_max_f32 %[f1], %[ay], %[by]\n\t"
+        "v_min_f32 %[n2], %[az], %[bz]\n\tv_max_f32 %[f2], %[az], %[bz]\n\t"
+        "v_max3_f32 %[n0], %[n0], %[n1], %[n2]\n\t"   // nearmax
+        "v_min3_f32 %[f0], %[f0], %[f1], %[f2]\n\t"   // farmin
+        "v_cmp_le_f32_e64 %[m0], %[n0], %[hiP]\n\tv_cmp_ge_f32_e64 %[m1], %[f0], %[loP]\n\t"
+        "v_cmp_gt_f32_e64 %[m2], %[n0], %[hiF]\n\tv_cmp_lt_f32_e64 %[m3], %[f0], %[loF]"
+        : [n0] "=&v"(n0), [n1] "=&v"(n1), [n2] "=&v"(n2), [f0] "=&v"(f0), [f1] "=&v"(f1), [f2] "=&v"(f2),
+          [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3)
+        : [ax] "v"(tx.x), [bx] "v"(tx.y), [ay] "v"(ty.x), [by] "v"(ty.y), [az] "v"(tz.x), [bz] "v"(tz.y),
+          [hiP] "v"(f.hiP), [loP] "v"(f.loP), [hiF] "v"(f.hiF), [loF] "v"(f.loF));
+    cp = m0 & m1;
+    cf = m2 | m3;
 }
 
 // ---- triangle filter -----------------------------------------------------------------------------------------------
@@ -270,18 +285,24 @@ RT_DEV lanemask tri_filter_one(float sh, float det, float ms, float md) {  // se
 }
 RT_DEV void tri_filter(const TriFilter& f, const Window& w, lanemask& rejA, lanemask& rejB) {
     f2 sh, det, ms, md;
-    PK_MUL(sh, tri_pair<0>(w), f.dz_mox, 1);            // e2.x * mo.x
-    PK_FMA_ACC(sh, tri_pair<1>(w), f.mo_yz, 0, sh);     // e2.y * mo.y
-    PK_FMA_ACC(sh, tri_pair<2>(w), f.mo_yz, 1, sh);     // e2.z * mo.z
-    PK_FMA_ACC(sh, tri_pair<3>(w), f.d_xy, 0, sh);      // ml.x * d.x
-    PK_FMA_ACC(sh, tri_pair<4>(w), f.d_xy, 1, sh);      // ml.y * d.y
-    PK_FMA_ACC(sh, tri_pair<5>(w), f.dz_mox, 0, sh);    // ml.z * d.z
-    PK_MUL(det, tri_pair<6>(w), f.d_xy, 0);             // -n.x * d.x
-    PK_FMA_ACC(det, tri_pair<7>(w), f.d_xy, 1, det);    // -n.y * d.y
-    PK_FMA_ACC(det, tri_pair<8>(w), f.dz_mox, 0, det);  // -n.z * d.z
-    PK_MUL(ms, tri_pair<10>(w), f.D_MO, 0);             // ML' * D
-    PK_FMA_ACC(ms, tri_pair<9>(w), f.D_MO, 1, ms);      // E2' * MO'
-    PK_MUL(md, tri_pair<11>(w), f.D_MO, 0);             // N'' * D
+    // one asm block (see box_filter); op_sel picks the low / high half of the per-lane pair for both triangles
+    asm("v_pk_mul_f32 %[sh], %[e2x], %[dzmx] op_sel:[0,1] op_sel_hi:[1,1]\n\t"            // e2.x * mo.x
+        "v_pk_mul_f32 %[det], %[nx], %[dxy] op_sel:[0,0] op_sel_hi:[1,0]\n\t"             // -n.x * d.x
+        "v_pk_mul_f32 %[ms], %[ML], %[DMO] op_sel:[0,0] op_sel_hi:[1,0]\n\t"              // ML' * D
+        "v_pk_mul_f32 %[md], %[NN], %[DMO] op_sel:[0,0] op_sel_hi:[1,0]\n\t"              // N'' * D
+        "v_pk_fma_f32 %[sh], %[e2y], %[moyz], %[sh] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"  // e2.y * mo.y
+        "v_pk_fma_f32 %[det], %[ny], %[dxy], %[det] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"  // -n.y * d.y
+        "v_pk_fma_f32 %[ms], %[E2], %[DMO], %[ms] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"    // E2' * MO'
+        "v_pk_fma_f32 %[sh], %[e2z], %[moyz], %[sh] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"  // e2.z * mo.z
+        "v_pk_fma_f32 %[det], %[nz], %[dzmx], %[det] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t" // -n.z * d.z
+        "v_pk_fma_f32 %[sh], %[mlx], %[dxy], %[sh] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"   // ml.x * d.x
+        "v_pk_fma_f32 %[sh], %[mly], %[dxy], %[sh] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"   // ml.y * d.y
+        "v_pk_fma_f32 %[sh], %[mlz], %[dzmx], %[sh] op_sel:[0,0,0] op_sel_hi:[1,0,1]"       // ml.z * d.z
+        : [sh] "=&v"(sh), [det] "=&v"(det), [ms] "=&v"(ms), [md] "=&v"(md)
+        : [e2x] "s"(tri_pair<0>(w)), [e2y] "s"(tri_pair<1>(w)), [e2z] "s"(tri_pair<2>(w)), [mlx] "s"(tri_pair<3>(w)), [mly] "s"(tri_pair<4>(w)),
+          [mlz] "s"(tri_pair<5>(w)), [nx] "s"(tri_pair<6>(w)), [ny] "s"(tri_pair<7>(w)), [nz] "s"(tri_pair<8>(w)), [E2] "s"(tri_pair<9>(w)),
+          [ML] "s"(tri_pair<10>(w)), [NN] "s"(tri_pair<11>(w)),
+          [dxy] "v"(f.d_xy), [dzmx] "v"(f.dz_mox), [moyz] "v"(f.mo_yz), [DMO] "v"(f.D_MO));
     rejA = tri_filter_one(sh.x, det.x, ms.x, md.x);
     rejB = tri_filter_one(sh.y, det.y, ms.y, md.y);
 }
