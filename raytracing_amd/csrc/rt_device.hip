@@ -111,6 +111,7 @@ RT_DEV GeomS load_geom(cptr<rt_geom> geom, uint32_t p) {
 //     + for a leaf of one triangle (block repeats it) or two under one transform (RT_STREAM_TRI2), 112 B:
 //       xform id | pad | 12 fp32 (A, B) pairs: e2.xyz, ml.xyz = v0 x e2, -n.xyz = -(e1 x e2), E2', ML', N'' (error weights)
 //     + for a leaf of one or two spheres under one transform (RT_STREAM_SPH2), 80 B: xform id | count | (centre, radius) f64 x 2
+//     + for any other leaf (RT_STREAM_LEAF), 16 B: prim0 | prim1 | xform of prim0 | pad
 // Every range (the scene-level array, each instance sub-array) is closed by an END record -- a list-item header that
 // every ray passes -- so the walk needs no bounds test: skip links to the end of a range land on it.
 // A traversal step loads one window of the stream (two s_load_dwordx16 + one dwordx2 issued back to back,
@@ -130,6 +131,7 @@ RT_DEV GeomS load_geom(cptr<rt_geom> geom, uint32_t p) {
 #define RT_STREAM_LEAF 8u      /* any other leaf: exact tests on the blob's own tables */
 #define RT_STREAM_SPH2 12u     /* leaf of one or two spheres under the same transform, f64 geometry inline */
 #define RT_STREAM_REC_SPH2 112u
+#define RT_STREAM_REC_LEAF 48u     /* header + prim0 | prim1 | xform of prim0 | pad: the exact path starts its geometry loads without a detour through rt_node */
 #define RT_STREAM_REC 32u
 #define RT_STREAM_REC_TRI2 144u
 #define RT_STREAM_PAD 384u     /* readable bytes past the last record: the window over-reads */
@@ -547,15 +549,15 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
                 }
             } else {  // any other leaf: exact tests on the blob's tables
                 if (node == RT_STREAM_END_NODE) { want = RT_WALK_DONE; break; }  // END record: every ray still waiting has arrived at the end of the range
-                const uint32_t p0 = nodes[node].prim0, p1 = nodes[node].prim1;
-                const GeomS g0 = load_geom(geom, p0);
+                const uint32_t p0 = wword<8>(w), p1 = wword<9>(w);
                 const bool pass = mask_lane(m_pass);
-                if (g0.xform != cur_xf) {
+                if (wword<10>(w) != cur_xf) {
                     if (COUNT && !(rec & RT_NODE_NO_BOX)) cnt.box -= pass ? 1u : 0u;
-                    want = g0.xform;
+                    want = wword<10>(w);
                     break;
                 }
-                off += RT_STREAM_REC;
+                off += RT_STREAM_REC_LEAF;
+                const GeomS g0 = load_geom(geom, p0);
                 const RayS ray = src.get();
                 d3 xo, xd;
                 apply_xform(sc, cur_xf, ray, xo, xd);
@@ -1343,7 +1345,7 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     for (uint32_t i = 0; i <= h.n_nodes; ++i) {
         if (ends_here[i]) { end_off[i] = (uint32_t)stream_bytes; stream_bytes += RT_STREAM_REC; }  // END record of the range(s) ending here
         rec_off[i] = (uint32_t)stream_bytes;
-        if (i < h.n_nodes) stream_bytes += is_tri2(nodes[i]) ? RT_STREAM_REC_TRI2 : is_sph2(nodes[i]) ? RT_STREAM_REC_SPH2 : RT_STREAM_REC;
+        if (i < h.n_nodes) stream_bytes += is_tri2(nodes[i]) ? RT_STREAM_REC_TRI2 : is_sph2(nodes[i]) ? RT_STREAM_REC_SPH2 : nodes[i].prim0 != RT_NONE ? RT_STREAM_REC_LEAF : RT_STREAM_REC;
         if (stream_bytes + RT_STREAM_PAD > 0xFFFFFFF0ull) { delete sc; return fail(RT_ERR_UNSUPPORTED, "trace stream larger than 4 GiB"); }
     }
     // a link to the end of the node's own range lands on that range's END record
@@ -1369,7 +1371,7 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
         const bool nb = (nd.flags & RT_NODE_NO_BOX) != 0, tri2 = is_tri2(nd), sph2 = is_sph2(nd);
         uint32_t fl = nd.flags & (RT_NODE_NO_BOX | RT_NODE_DUP_RIGHT);
         fl |= tri2 ? RT_STREAM_TRI2 : sph2 ? RT_STREAM_SPH2 : nd.prim0 != RT_NONE ? RT_STREAM_LEAF : RT_STREAM_INNER;
-        const uint32_t rec_bytes = tri2 ? RT_STREAM_REC_TRI2 : sph2 ? RT_STREAM_REC_SPH2 : RT_STREAM_REC;
+        const uint32_t rec_bytes = tri2 ? RT_STREAM_REC_TRI2 : sph2 ? RT_STREAM_REC_SPH2 : nd.prim0 != RT_NONE ? RT_STREAM_REC_LEAF : RT_STREAM_REC;
         float box[6];
         for (int k = 0; k < 3; ++k) {  // list items have no box in the reference: see the box filter
             box[2 * k] = nb ? -std::numeric_limits<float>::infinity() : (float)nd.bmin[k];
@@ -1378,6 +1380,10 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
         }
         const uint32_t words[2] = {link_off(i, nd.skip), fl | ((rec_bytes / 16u) << 4) | (i << 8)};
         memcpy(rec, box, 24); memcpy(rec + 24, words, 8);
+        if (!tri2 && !sph2 && nd.prim0 != RT_NONE) {
+            const uint32_t ids[4] = {nd.prim0, nd.prim1, geom[nd.prim0].xform, 0u};
+            memcpy(rec + RT_STREAM_REC, ids, 16);
+        }
         if (sph2) {
             const uint32_t head[2] = {geom[nd.prim0].xform, nd.prim1 != RT_NONE ? 2u : 1u};
             memcpy(rec + RT_STREAM_REC, head, 8);
