@@ -193,6 +193,15 @@ int rt_context_synchronize(rt_context* ctx);
 /* Validates and copies the flattened blob to the device (caller keeps `blob`). */
 int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene** out);
 int rt_scene_destroy(rt_scene* scene);
+/* Host only (no HIP call; works without a GPU): runs the validation of rt_scene_upload and writes the trace stream
+ * rt_scene_upload derives from the blob (pre-order records, 32 B header = fp32 box |
+ * skip offset | flags/size/node word, leaf blocks behind it) to stream_out (may be NULL to query the size).
+ * *stream_bytes = size including the zero padding the kernel's window over-reads; *root_off = offset of the first
+ * record of the scene-level array; node_off (may be NULL) = n_nodes + 1 record offsets, by node index.
+ * No counterpart in the reference (the stream replaces the pointer tree of bvh.rs:15-23 on the device): it
+ * exists so that tests without a GPU can check what the kernel will walk. */
+int rt_stream_build_host(const void* blob, uint64_t nbytes, void* stream_out, uint64_t capacity, uint64_t* stream_bytes,
+                         uint32_t* root_off, uint32_t* node_off);
 
 /* Scene::hit for n rays (scene.rs:31-38).  rays: n x 7 doubles (ox,oy,oz,dx,dy,dz,time), host.
  * Outputs (host): prim_id = object id of the closest primitive or RT_NONE; inst_id = enclosing

@@ -78,6 +78,20 @@ class HostScene:
                                                 ("object_id", "<u4"), ("inst_id", "<u4"), ("sub_end", "<u4"), ("pad", "<u4")]),
                              count=h.n_prims, offset=h.off_prims)
 
+    def geoms(self):
+        b, h = self.blob(), self.header()
+        return np.frombuffer(b, dtype=np.dtype([("d", "<f8", 9), ("kind", "<u4"), ("xform", "<u4")]), count=h.n_prims, offset=h.off_geom)
+
+    def trace_stream(self):
+        """The device trace stream rt_scene_upload derives from this scene, built on the host (no GPU needed):
+        (stream bytes as uint8 array incl. padding, offset of the root record, record offset per node index)."""
+        b, h = self.blob(), self.header()
+        n, root = _ffi.u64(), _ffi.u32()
+        _hip_check(_ffi.hip().rt_stream_build_host(b, len(b), None, 0, C.byref(n), C.byref(root), None))
+        out = np.zeros(n.value, np.uint8); off = np.zeros(h.n_nodes + 1, np.uint32)
+        _hip_check(_ffi.hip().rt_stream_build_host(b, len(b), out.ctypes.data, out.nbytes, C.byref(n), C.byref(root), off.ctypes.data))
+        return out, int(root.value), off
+
     def __del__(self):
         try:
             if self._h:

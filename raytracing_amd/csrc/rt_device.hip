@@ -1254,10 +1254,19 @@ static bool range_ok(uint64_t off, uint64_t count, uint64_t elem, uint64_t total
     return off % 16 == 0 && off <= total && count * elem <= total - off;
 }
 
-int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene** out) {
-    if (!ctx || !blob || !out) return fail(RT_ERR_BAD_ARG, "rt_scene_upload: null argument");
-    if (nbytes < sizeof(rt_blob_header)) return fail(RT_ERR_BAD_BLOB, "blob smaller than its header");
+// Everything rt_scene_upload derives from a blob without touching the device: validation of every index the kernels
+// follow, and the trace stream.  Also behind rt_stream_build_host, so the CPU-only tests can check the stream.
+struct ScenePrep {
     rt_blob_header h;
+    bool boxes_finite = true, reg_ray = false, has_instances = false;
+    std::vector<uint8_t> uses_uv, stream;
+    std::vector<uint32_t> rec_off, end_off;
+    double box_abs_max = 0.0;
+    uint32_t root_off = 0;
+};
+static int prepare_scene(const void* blob, uint64_t nbytes, ScenePrep& P) {
+    if (nbytes < sizeof(rt_blob_header)) return fail(RT_ERR_BAD_BLOB, "blob smaller than its header");
+    rt_blob_header& h = P.h;
     memcpy(&h, blob, sizeof h);
     if (h.magic != RT_BLOB_MAGIC || h.version != RT_BLOB_VERSION) return fail(RT_ERR_BAD_BLOB, "bad blob magic/version");
     if (h.total_bytes != nbytes) return fail(RT_ERR_BAD_BLOB, "blob size mismatch");
@@ -1275,7 +1284,7 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     const rt_material* mats = (const rt_material*)(b + h.off_materials);
     const rt_texture* tex = (const rt_texture*)(b + h.off_textures);
     if (h.root_node > h.root_end || h.root_end > h.n_nodes) return fail(RT_ERR_BAD_BLOB, "root range out of bounds");
-    bool boxes_finite = true;
+    bool& boxes_finite = P.boxes_finite;
     for (uint32_t i = 0; i < h.n_nodes; ++i) {
         for (int k = 0; k < 3 && !(nodes[i].flags & RT_NODE_NO_BOX); ++k)
             boxes_finite = boxes_finite && std::isfinite(nodes[i].bmin[k]) && std::isfinite(nodes[i].bmax[k]) && nodes[i].bmin[k] <= nodes[i].bmax[k];
@@ -1305,7 +1314,8 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     }
     for (uint32_t k = h.root_node; k < h.root_end; ++k)
         if (nodes[k].skip > h.root_end) return fail(RT_ERR_BAD_BLOB, "scene-level skip link leaves the scene array");
-    std::vector<uint8_t> uses_uv(std::max<uint32_t>(h.n_materials, 1), 0);
+    std::vector<uint8_t>& uses_uv = P.uses_uv;
+    uses_uv.assign(std::max<uint32_t>(h.n_materials, 1), 0);
     for (uint32_t i = 0; i < h.n_textures; ++i) {
         if (tex[i].kind > RT_TEX_IMAGE) return fail(RT_ERR_BAD_BLOB, "texture kind");
         if (tex[i].kind == RT_TEX_CHECKER && (tex[i].a >= h.n_textures || tex[i].b >= h.n_textures)) return fail(RT_ERR_BAD_BLOB, "checker child out of range");
@@ -1332,14 +1342,9 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     for (uint32_t i = 0; i < h.n_lights; ++i)
         if (lights[i].material >= h.n_materials) return fail(RT_ERR_BAD_BLOB, "light material out of range");
 
-    HIP_OK(hipSetDevice(ctx->device));
-    rt_scene* sc = new (std::nothrow) rt_scene();
-    if (!sc) return fail(RT_ERR_OOM, "host allocation failed");
-    sc->ctx = ctx; sc->hdr = h;
-    sc->host_prims.assign(prims, prims + h.n_prims);
-    for (uint32_t i = 0; i < h.n_prims; ++i) sc->has_instances = sc->has_instances || prims[i].kind == RT_PRIM_INSTANCE;
+    for (uint32_t i = 0; i < h.n_prims; ++i) P.has_instances = P.has_instances || prims[i].kind == RT_PRIM_INSTANCE;
     // trace stream: pre-order fp32 filter records (see k_trace)
-    if (h.n_nodes >= RT_STREAM_MAX_NODES) { delete sc; return fail(RT_ERR_UNSUPPORTED, "more than 2^24 BVH nodes"); }
+    if (h.n_nodes >= RT_STREAM_MAX_NODES) { return fail(RT_ERR_UNSUPPORTED, "more than 2^24 BVH nodes"); }
     auto is_tri2 = [&](const rt_node& nd) {  // one triangle, or two under the same transform: leaf with a filter block
         if (nd.prim0 == RT_NONE || geom[nd.prim0].kind != RT_PRIM_TRIANGLE) return false;
         return nd.prim1 == RT_NONE || (geom[nd.prim1].kind == RT_PRIM_TRIANGLE && geom[nd.prim0].xform == geom[nd.prim1].xform);
@@ -1359,13 +1364,14 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
             for (uint32_t k = prims[i].index; k < prims[i].sub_end; ++k) range_end[k] = prims[i].sub_end;
             ends_here[prims[i].sub_end] = 1;
         }
-    std::vector<uint32_t> rec_off((size_t)h.n_nodes + 1), end_off((size_t)h.n_nodes + 1, 0);
+    std::vector<uint32_t>& rec_off = P.rec_off; std::vector<uint32_t>& end_off = P.end_off;
+    rec_off.assign((size_t)h.n_nodes + 1, 0); end_off.assign((size_t)h.n_nodes + 1, 0);
     uint64_t stream_bytes = 0;
     for (uint32_t i = 0; i <= h.n_nodes; ++i) {
         if (ends_here[i]) { end_off[i] = (uint32_t)stream_bytes; stream_bytes += RT_STREAM_REC; }  // END record of the range(s) ending here
         rec_off[i] = (uint32_t)stream_bytes;
         if (i < h.n_nodes) stream_bytes += is_tri2(nodes[i]) ? RT_STREAM_REC_TRI2 : is_sph2(nodes[i]) ? RT_STREAM_REC_SPH2 : nodes[i].prim0 != RT_NONE ? RT_STREAM_REC_LEAF : RT_STREAM_REC;
-        if (stream_bytes + RT_STREAM_PAD > 0xFFFFFFF0ull) { delete sc; return fail(RT_ERR_UNSUPPORTED, "trace stream larger than 4 GiB"); }
+        if (stream_bytes + RT_STREAM_PAD > 0xFFFFFFF0ull) { return fail(RT_ERR_UNSUPPORTED, "trace stream larger than 4 GiB"); }
     }
     // a link to the end of the node's own range lands on that range's END record
     auto link_off = [&](uint32_t from, uint32_t to) { return to == range_end[from] ? end_off[to] : rec_off[to]; };
@@ -1375,7 +1381,8 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
         if ((double)f < v) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
         return f;
     };
-    std::vector<uint8_t> stream((size_t)stream_bytes + RT_STREAM_PAD, 0);
+    std::vector<uint8_t>& stream = P.stream;
+    stream.assign((size_t)stream_bytes + RT_STREAM_PAD, 0);
     for (uint32_t e = 0; e <= h.n_nodes; ++e) {
         if (!ends_here[e]) continue;
         const float inf = std::numeric_limits<float>::infinity();
@@ -1383,7 +1390,7 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
         const uint32_t words[2] = {end_off[e], RT_NODE_NO_BOX | RT_STREAM_LEAF | ((RT_STREAM_REC / 16u) << 4) | (RT_STREAM_END_NODE << 8)};
         memcpy(stream.data() + end_off[e], box, 24); memcpy(stream.data() + end_off[e] + 24, words, 8);
     }
-    double box_abs_max = 0.0;
+    double& box_abs_max = P.box_abs_max;
     for (uint32_t i = 0; i < h.n_nodes; ++i) {
         const rt_node& nd = nodes[i];
         uint8_t* rec = stream.data() + rec_off[i];
@@ -1435,8 +1442,47 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     {
         uint64_t n_leaf = 0, n_tri_leaf = 0;
         for (uint32_t i = 0; i < h.n_nodes; ++i) { n_leaf += nodes[i].prim0 != RT_NONE; n_tri_leaf += is_tri2(nodes[i]); }
-        sc->reg_ray = 2 * n_tri_leaf < n_leaf;
+        P.reg_ray = 2 * n_tri_leaf < n_leaf;
     }
+    P.root_off = h.root_node == h.root_end ? end_off[h.root_end] : rec_off[h.root_node];
+    return RT_OK;
+}
+
+int rt_stream_build_host(const void* blob, uint64_t nbytes, void* stream_out, uint64_t capacity, uint64_t* stream_bytes, uint32_t* root_off, uint32_t* node_off) {
+    if (!blob || !stream_bytes) return fail(RT_ERR_BAD_ARG, "rt_stream_build_host: null argument");
+    ScenePrep P;
+    int rc = prepare_scene(blob, nbytes, P);
+    if (rc != RT_OK) return rc;
+    *stream_bytes = P.stream.size();
+    if (root_off) *root_off = P.root_off;
+    if (stream_out) {
+        if (capacity < P.stream.size()) return fail(RT_ERR_BAD_ARG, "rt_stream_build_host: buffer too small");
+        memcpy(stream_out, P.stream.data(), P.stream.size());
+    }
+    if (node_off) memcpy(node_off, P.rec_off.data(), P.rec_off.size() * sizeof(uint32_t));
+    return RT_OK;
+}
+
+int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene** out) {
+    if (!ctx || !blob || !out) return fail(RT_ERR_BAD_ARG, "rt_scene_upload: null argument");
+    ScenePrep P;
+    {
+        int rc = prepare_scene(blob, nbytes, P);
+        if (rc != RT_OK) return rc;
+    }
+    const rt_blob_header& h = P.h;
+    const uint8_t* b = (const uint8_t*)blob;
+    const rt_node* nodes = (const rt_node*)(b + h.off_nodes);
+    const rt_prim* prims = (const rt_prim*)(b + h.off_prims);
+    const std::vector<uint8_t>& uses_uv = P.uses_uv; const std::vector<uint8_t>& stream = P.stream;
+    const std::vector<uint32_t>& rec_off = P.rec_off;
+    const bool boxes_finite = P.boxes_finite; const double box_abs_max = P.box_abs_max;
+    HIP_OK(hipSetDevice(ctx->device));
+    rt_scene* sc = new (std::nothrow) rt_scene();
+    if (!sc) return fail(RT_ERR_OOM, "host allocation failed");
+    sc->ctx = ctx; sc->hdr = h;
+    sc->host_prims.assign(prims, prims + h.n_prims);
+    sc->has_instances = P.has_instances; sc->reg_ray = P.reg_ray;
     hipError_t e = hipMalloc(&sc->dblob, nbytes);
     if (e == hipSuccess) e = hipMalloc((void**)&sc->d_mat_uses_uv, uses_uv.size());
     if (e == hipSuccess) e = hipMalloc((void**)&sc->d_stream, stream.size());
@@ -1461,7 +1507,7 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     v.materials = (const rt_material*)(d + h.off_materials); v.textures = (const rt_texture*)(d + h.off_textures);
     v.texels = d + h.off_texels; v.lights = (const rt_light*)(d + h.off_lights);
     v.mat_uses_uv = sc->d_mat_uses_uv;
-    v.stream = sc->d_stream; v.root_off = h.root_node == h.root_end ? end_off[h.root_end] : rec_off[h.root_node];
+    v.stream = sc->d_stream; v.root_off = P.root_off;
     v.node_off = sc->d_node_off; v.box_abs_max = box_abs_max;
     v.n_nodes = h.n_nodes; v.boxes_finite = boxes_finite ? 1u : 0u;
     v.camera = h.camera; v.n_lights = h.n_lights; v.root_node = h.root_node; v.root_end = h.root_end; v.background = h.background;

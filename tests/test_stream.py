@@ -1,0 +1,214 @@
+"""CPU tests (-m "not gpu") of the trace stream k_trace walks, built on the host by
+rt_stream_build_host -- the same code path rt_scene_upload runs before its first HIP call.
+
+Checked here, without a GPU: every record is well-formed and sits where the node table says, skip links land on
+record starts of the same range or on that range's END record, the fp32 boxes / triangle blocks / sphere blocks
+restate the blob's f64 tables, the error weights of the triangle filter are upper bounds, and walking the
+stream (links only) visits exactly what the reference's recursion visits (bvh.rs:91-106), compared through the
+oracle's box-test counts."""
+import struct
+
+import numpy as np
+import pytest
+
+import oracle_ffi as orc
+import raytracing_amd as rt
+from scene_text import SceneText, scale, translate
+
+NO_BOX, DUP_RIGHT = 1, 2
+INNER, TRI2, LEAF, SPH2 = 0, 4, 8, 12
+REC_BYTES = {INNER: 32, TRI2: 144, LEAF: 48, SPH2: 112}
+END_NODE = 0xFFFFFF
+PAD = 384
+SCENES = ["random", "cornell", "simple", "simple_triangle", "mesh", "simple_light", "sphere", "random_blur"]
+
+
+def _records(stream):
+    """Parses the stream front to back: list of dicts (off, box[6], skip, flags, kind, size, node)."""
+    out, off, end = [], 0, len(stream) - PAD
+    raw = stream.tobytes()
+    while off < end:
+        box = struct.unpack_from("<6f", raw, off)
+        skip, word = struct.unpack_from("<2I", raw, off + 24)
+        r = dict(off=off, box=box, skip=skip, flags=word & 3, kind=word & 12, size=((word >> 4) & 15) * 16, node=word >> 8)
+        assert r["size"] == (32 if r["node"] == END_NODE else REC_BYTES[r["kind"]]), r
+        out.append(r)
+        off += r["size"]
+    assert off == end and not stream[end:].any()          # records tile the stream exactly; the over-read pad is zero
+    return out
+
+
+def _ranges(hs):
+    h, pr = hs.header(), hs.prims()
+    rs = [(h.root_node, h.root_end)]
+    rs += sorted({(int(p["index"]), int(p["sub_end"])) for p in pr if p["kind"] == 4})
+    return rs
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_stream_structure(name):
+    hs = rt.HostScene.builtin(name, bvh_seed=2, legacy_bvh=(name == "simple_triangle"))
+    h, nodes, pr, geo = hs.header(), hs.nodes(), hs.prims(), hs.geoms()
+    stream, root_off, node_off = hs.trace_stream()
+    recs = _records(stream)
+    by_off = {r["off"]: r for r in recs}
+    real = [r for r in recs if r["node"] != END_NODE]
+    ends = [r for r in recs if r["node"] == END_NODE]
+    assert [r["node"] for r in real] == list(range(h.n_nodes))            # pre-order = node index order
+    assert [r["off"] for r in real] == list(node_off[:h.n_nodes])
+    ranges = _ranges(hs)
+    assert len(ends) == len({e for _, e in ranges})                        # one END per distinct range end
+    inf = float("inf")
+    for e in ends:
+        assert e["box"] == (-inf, inf, -inf, inf, -inf, inf) and e["flags"] == NO_BOX and e["kind"] == LEAF and e["skip"] == e["off"]
+    assert root_off == (node_off[h.root_node] if h.root_end > h.root_node else ends[0]["off"])
+    # END of a range sits directly behind the range's last record
+    end_of = {}
+    for b, e in ranges:
+        last = by_off[int(node_off[e - 1])]
+        nxt = by_off[last["off"] + last["size"]]
+        assert nxt["node"] == END_NODE
+        end_of[e] = nxt["off"]
+    range_end = np.zeros(h.n_nodes, np.int64)
+    for b, e in ranges:
+        range_end[b:e] = e
+    raw = stream.tobytes()
+    for r in real:
+        i = r["node"]; nd = nodes[i]
+        assert r["flags"] == int(nd["flags"]) & 3
+        # links: inside the range -> that node's record; to the range end -> the END record
+        tgt = int(nd["skip"])
+        assert r["skip"] == (end_of[tgt] if tgt == range_end[i] else int(node_off[tgt])), (i, tgt)
+        assert r["skip"] > r["off"]
+        if r["flags"] & NO_BOX:
+            assert r["box"] == (-inf, inf, -inf, inf, -inf, inf)
+        else:
+            want = np.stack([nd["bmin"], nd["bmax"]], axis=1).reshape(6).astype(np.float32)
+            assert np.array_equal(np.array(r["box"], np.float32), want)
+        p0, p1 = int(nd["prim0"]), int(nd["prim1"])
+        if p0 == rt.NONE:
+            assert r["kind"] == INNER and p1 == rt.NONE
+            continue
+        kinds = [int(geo[p]["kind"]) for p in (p0, p1) if p != rt.NONE]
+        same_xf = p1 == rt.NONE or geo[p0]["xform"] == geo[p1]["xform"]
+        if all(k == 0 for k in kinds) and same_xf:
+            assert r["kind"] == TRI2
+            xf, = struct.unpack_from("<I", raw, r["off"] + 32)
+            assert xf == int(geo[p0]["xform"])
+            blk = np.frombuffer(raw, np.float32, 24, r["off"] + 40).reshape(12, 2)
+            for t, p in enumerate((p0, p1 if p1 != rt.NONE else p0)):     # a single triangle fills both halves
+                v0, e1, e2 = geo[p]["d"][:3], geo[p]["d"][3:6], geo[p]["d"][6:9]
+                ml, nn = np.cross(v0, e2), np.cross(e1, e2)
+                assert np.array_equal(blk[0:3, t], e2.astype(np.float32))
+                assert np.allclose(blk[3:6, t], ml, rtol=1e-6, atol=1e-30) and np.allclose(blk[6:9, t], -nn, rtol=1e-6, atol=1e-30)
+                # error weights are upper bounds of the analytic expressions, rounded up
+                n1 = lambda v: np.abs(v).sum()
+                ni = lambda v: np.abs(v).max()
+                assert float(blk[9, t]) >= 2.0 ** -20 * ni(e2)
+                assert float(blk[10, t]) >= 2.0 ** -20 * n1(ml) + 2.0 ** -46 * ni(v0) * n1(e2)
+                assert float(blk[11, t]) >= (1 + 2.0 ** -19) * (2.0 ** -20 * n1(nn) + 2.0 ** -46 * n1(e1) * n1(e2))
+                # ... and tight: not more than a few ulps above them
+                assert float(blk[9, t]) <= 2.0 ** -20 * ni(e2) * (1 + 1e-6) + 1e-44
+        elif all(k == 1 for k in kinds) and same_xf:
+            assert r["kind"] == SPH2
+            xf, cnt = struct.unpack_from("<2I", raw, r["off"] + 32)
+            assert xf == int(geo[p0]["xform"]) and cnt == len(kinds)
+            sp = np.frombuffer(raw, np.float64, 4 * cnt, r["off"] + 40).reshape(cnt, 4)
+            for t, p in enumerate([p for p in (p0, p1) if p != rt.NONE]):
+                assert np.array_equal(sp[t].view(np.uint64), geo[p]["d"][:4].view(np.uint64))
+        else:
+            assert r["kind"] == LEAF
+            assert struct.unpack_from("<3I", raw, r["off"] + 32) == (p0, p1, int(geo[p0]["xform"]))
+
+
+def _walk(stream, start, decide):
+    """k_trace's control flow over the stream, links only: decide(record) -> does its box pass.
+    Returns the node indices whose record was reached."""
+    raw = stream.tobytes()
+    off, seen = start, []
+    for _ in range(1 << 22):
+        skip, word = struct.unpack_from("<2I", raw, off + 24)
+        node, kind, size = word >> 8, word & 12, ((word >> 4) & 15) * 16
+        if node == END_NODE:
+            return seen
+        seen.append(node)
+        off = off + size if decide(node, word & 3, kind) else skip
+    raise AssertionError("walk did not reach an END record")
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_walks_terminate_and_cover_each_range(name):
+    hs = rt.HostScene.builtin(name, bvh_seed=6, legacy_bvh=(name == "simple_triangle"))
+    nodes = hs.nodes()
+    stream, root_off, node_off = hs.trace_stream()
+    for b, e in _ranges(hs):
+        start = root_off if (b, e) == _ranges(hs)[0] else int(node_off[b])
+        assert _walk(stream, start, lambda n, f, k: True) == list(range(b, e))       # every box passes: every node once, in order
+        # every box fails: only the nodes no other node of the range contains (skip chain from the first)
+        top, i = [], b
+        while i < e:
+            top.append(i); i = int(nodes[i]["skip"])
+        assert _walk(stream, start, lambda n, f, k: False) == top
+
+
+@pytest.mark.parametrize("name,seed", [("random", 1), ("random", 8), ("mesh", 3), ("simple_triangle", 0)])
+def test_walk_visits_what_the_reference_recursion_visits(name, seed):
+    # Rays with a hit window [t0, t0 + 1e-12]: a box passes when the ray point at t0 lies in it, practically no surface
+    # does, so t_max never shrinks and the oracle's box-test count (bvh.rs:91-106: one per node reached, list items of
+    # hittable.rs:41-53 have none) must equal the number of box-carrying records the stream walk reaches.
+    hs = rt.HostScene.builtin(name, bvh_seed=seed, legacy_bvh=(name == "simple_triangle"))
+    osc = orc.OracleScene(hs.describe())
+    h, nodes = hs.header(), hs.nodes()
+    stream, root_off, _ = hs.trace_stream()
+    rays = osc.primary_rays(24, 14, 0, 0x5EED)[::3]
+    rng = np.random.default_rng(seed)
+    t0 = rng.uniform(5.0, 60.0, len(rays))
+    total, n_rays = 0, 0
+    for ray, t in zip(rays, t0):
+        prim, _, _, cnt = osc.trace_closest(ray[None, :], t, t + 1e-12)
+        if prim[0] != rt.NONE:
+            continue                                                               # (never seen; keeps the premise honest)
+        n_rays += 1
+
+        def decide(n, fl, kind):
+            if fl & NO_BOX:
+                return True
+            return bool(orc.aabb_hit(np.concatenate([nodes[n]["bmin"], nodes[n]["bmax"]]), ray, t, t + 1e-12))
+        seen = _walk(stream, root_off, decide)
+        boxed = sum(1 for n in seen if not (int(nodes[n]["flags"]) & NO_BOX))
+        assert boxed == int(cnt[0]), (boxed, cnt)
+        total += boxed
+    assert n_rays > len(rays) // 2 and total > n_rays                              # the walks did descend
+
+
+def test_stream_of_lists_instances_and_odd_leaves():
+    # list scene (no BVH: every record NO_BOX), instances (sub-ranges with their own END), mixed leaves
+    s = SceneText(bvh_seed=1)
+    m = s.lambertian_rgb(.5, .5, .5)
+    a = s.sphere((0, 0, 0), 1.0, m)
+    b = s.transformed(s.xform(translate(3, 0, 0)), s.sphere((0, 0, 0), 0.5, m))
+    r = s.aarect(-1, 1, -1, 1, 2.0, m)
+    hs = rt.HostScene.from_description(s.finish([a, b, r]))
+    stream, root_off, node_off = hs.trace_stream()
+    recs = _records(stream)
+    assert [x["flags"] & NO_BOX for x in recs] == [1, 1, 1, 1]
+    assert [x["kind"] for x in recs] == [SPH2, SPH2, LEAF, LEAF] and recs[-1]["node"] == END_NODE
+    assert _walk(stream, root_off, lambda n, f, k: False) == [0, 1, 2]            # no boxes to fail: a list tests everything
+    hs = rt.HostScene.builtin("cornell", bvh_seed=1)
+    recs = _records(hs.trace_stream()[0])
+    assert sum(1 for x in recs if x["node"] == END_NODE) == 1 + 4                  # scene array + 4 distinct cube BVHs
+
+
+def test_stream_builder_rejects_what_upload_rejects():
+    hs = rt.HostScene.builtin("sphere")
+    blob = bytearray(hs.blob())
+    n = rt._ffi.u64()
+    lib = rt._ffi.hip()
+    assert lib.rt_stream_build_host(bytes(blob[:100]), 100, None, 0, rt.C.byref(n), None, None) != 0
+    blob[0] ^= 0xFF                                                              # magic
+    assert lib.rt_stream_build_host(bytes(blob), len(blob), None, 0, rt.C.byref(n), None, None) != 0
+    good = hs.blob()
+    assert lib.rt_stream_build_host(good, len(good), None, 0, rt.C.byref(n), None, None) == 0
+    small = np.zeros(16, np.uint8)
+    assert lib.rt_stream_build_host(good, len(good), small.ctypes.data, small.nbytes, rt.C.byref(n), None, None) != 0
+    assert b"too small" in lib.rt_last_error()
