@@ -400,6 +400,9 @@ RT_DEV bool test_prim(const SceneDev& sc, uint32_t p, const GeomS& g, bool pass,
 // (An octant-uniform form -- near/far planes picked by scalar selects -- measured slower: the scalar unit is
 // as loaded as the vector unit in this loop.)
 enum { BOX_LITERAL = 0, BOX_PLAIN = 1 };
+#ifndef RT_LEAF_FIRST
+#define RT_LEAF_FIRST 1
+#endif
 #define RT_WALK_DONE 0xFFFFFFFEu  /* `want` value that ends the walk (never a transform id: RT_NONE is 0xFFFFFFFF, ids are < n_xforms) */
 template <bool PLAIN>
 RT_DEV bool box_exact(cptr<rt_node> nodes, uint32_t rec, d3 o, d3 d, double t_min, double best) {
@@ -445,6 +448,41 @@ RT_DEV lanemask box_step(const Window& w, const BoxFilter& bf, uint32_t off, uin
     return m_pass;
 }
 
+// Exact f64 tests of a TRI2 leaf for the lanes of m_pass the filter did not reject (COUNT: for every lane of m_pass),
+// one triangle at a time (register pressure); the f64 ray is re-derived here rather than kept live across the hot loop.
+template <bool COUNT, int MODE, class RAYSRC, class HIT>
+RT_DEV void tri2_exact(const SceneDev& sc, uint32_t node, lanemask m_pass, lanemask rejA, lanemask rejB, const RAYSRC& src, uint32_t cur_xf, HIT& h,
+                       double t_min, uint32_t inst_prim, BoxFilter& bf, LaneCount& cnt) {
+    cptr<rt_node> nodes = as_const(sc.nodes);
+    cptr<rt_geom> geom = as_const(sc.geom);
+    const RayS ray = src.get();
+    d3 xo, xd;
+    apply_xform(sc, cur_xf, ray, xo, xd);
+    const bool pass = mask_lane(m_pass);
+    bool changed = false;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const lanemask m_rej = k == 0 ? rejA : rejB;
+        if (!COUNT && (m_pass & ~m_rej) == 0ull) continue;  // nobody needs this triangle
+        const uint32_t p = k == 0 ? nodes[node].prim0 : nodes[node].prim1;
+        if (p == RT_NONE) break;  // single-triangle leaf: its filter block repeats triangle A
+        const GeomS g = load_geom(geom, p);
+        const d3 v0 = mk(g.d[0], g.d[1], g.d[2]), e1 = mk(g.d[3], g.d[4], g.d[5]), e2 = mk(g.d[6], g.d[7], g.d[8]);
+        const bool rej = mask_lane(m_rej);
+        TriStage st;
+        double t;
+        const bool go = pass & (COUNT ? true : !rej) & tri_stage_a(v0, e1, e2, xo, xd, st);
+        if (go && tri_hit_tail(st, v0, e1, e2, xo, xd, t_min, h.best, t)) {
+            h.best = t; h.prim = p; h.inst = inst_prim; changed = true;
+            if (COUNT) cnt.bad += rej ? 1u : 0u;  // a filtered lane must be one the reference rejects
+        }
+    }
+    if (MODE == BOX_PLAIN && changed) box_filter_set_best(bf, h.best);
+#ifdef RT_TRACE_DIAG
+    cnt.exact_tri += 1;
+#endif
+}
+
 template <int LEVEL, bool COUNT, bool INST, int MODE, class RAYSRC, class HIT>
 RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src, HIT& h, bool active, double t_min,
                           uint32_t inst_prim, LaneCount& cnt) {
@@ -480,6 +518,22 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
 #ifdef RT_TRACE_DIAG
             cnt.cyc_wait += __builtin_readcyclecounter() - c0; cnt.steps += 1; cnt.leaf_steps += (rec & RT_STREAM_KIND) ? 1u : 0u;
 #endif
+            if (RT_LEAF_FIRST && MODE == BOX_PLAIN && !COUNT && (rec & RT_STREAM_KIND) == RT_STREAM_TRI2 && wword<8>(w) == cur_xf) {
+                // Common leaf, rays already in its space: triangle filter FIRST.  The leaf's box only gates its own
+                // triangle tests (skip == next record either way), so it is evaluated for a wave only when some ray is
+                // not certainly rejected by both triangles -- the weak box test of the reference passes most leaves
+                // of a ray that has no hit yet, so the box would rarely have saved the triangle filter anyway.
+                const lanemask m_act = mask_reached(off, wait);
+                lanemask rejA, rejB;
+                tri_filter(tf, w, rejA, rejB);
+                if ((m_act & ~(rejA & rejB)) != 0ull) {
+                    const lanemask m_pass = box_step<0, MODE, COUNT>(w, bf, off, wait, rec, nodes, src, h, t_min, cnt);
+                    if ((m_pass & ~(rejA & rejB)) != 0ull) tri2_exact<COUNT, MODE>(sc, node, m_pass, rejA, rejB, src, cur_xf, h, t_min, inst_prim, bf, cnt);
+                    RT_RECONVERGE();
+                }
+                off += RT_STREAM_REC_TRI2;
+                continue;
+            }
             lanemask m_pass = box_step<0, MODE, COUNT>(w, bf, off, wait, rec, nodes, src, h, t_min, cnt);
             if (m_pass == 0ull) {
                 off = skip;
@@ -536,34 +590,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
                 lanemask rejA, rejB;
                 tri_filter(tf, w, rejA, rejB);
                 if (COUNT || (m_pass & ~(rejA & rejB)) != 0ull) {  // rare: most tested triangles are nowhere near the rays
-                    // exact f64 tests, one triangle at a time (register pressure); the f64 ray is re-derived here
-                    // rather than kept live across the hot loop
-                    const RayS ray = src.get();
-                    d3 xo, xd;
-                    apply_xform(sc, cur_xf, ray, xo, xd);
-                    const bool pass = mask_lane(m_pass);
-                    bool changed = false;
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const lanemask m_rej = k == 0 ? rejA : rejB;
-                        if (!COUNT && (m_pass & ~m_rej) == 0ull) continue;  // nobody needs this triangle
-                        const uint32_t p = k == 0 ? nodes[node].prim0 : nodes[node].prim1;
-                        if (p == RT_NONE) break;  // single-triangle leaf: its filter block repeats triangle A
-                        const GeomS g = load_geom(geom, p);
-                        const d3 v0 = mk(g.d[0], g.d[1], g.d[2]), e1 = mk(g.d[3], g.d[4], g.d[5]), e2 = mk(g.d[6], g.d[7], g.d[8]);
-                        const bool rej = mask_lane(m_rej);
-                        TriStage st;
-                        double t;
-                        const bool go = pass & (COUNT ? true : !rej) & tri_stage_a(v0, e1, e2, xo, xd, st);
-                        if (go && tri_hit_tail(st, v0, e1, e2, xo, xd, t_min, h.best, t)) {
-                            h.best = t; h.prim = p; h.inst = inst_prim; changed = true;
-                            if (COUNT) cnt.bad += rej ? 1u : 0u;  // a filtered lane must be one the reference rejects
-                        }
-                    }
-                    if (MODE == BOX_PLAIN && changed) box_filter_set_best(bf, h.best);
-#ifdef RT_TRACE_DIAG
-                    cnt.exact_tri += 1;
-#endif
+                    tri2_exact<COUNT, MODE>(sc, node, m_pass, rejA, rejB, src, cur_xf, h, t_min, inst_prim, bf, cnt);
                     RT_RECONVERGE();
                 }
             } else {  // any other leaf: exact tests on the blob's tables
