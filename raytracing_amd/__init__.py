@@ -149,7 +149,7 @@ class GpuScene:
         rays = np.ascontiguousarray(rays, np.float64).reshape(-1, 7)
         n = rays.shape[0]
         prim = np.empty(n, np.uint32); inst = np.empty(n, np.uint32); t = np.empty(n, np.float64)
-        cnt = np.zeros(4, np.uint64)  # box, triangle, sphere tests; filter violations (must be 0)
+        cnt = np.zeros(8, np.uint64)  # box, triangle, sphere tests; filter violations (must be 0)
         _hip_check(_ffi.hip().rt_trace_closest(self._h, n, rays.ctypes.data, t_min, t_max, prim.ctypes.data, inst.ctypes.data,
                                                t.ctypes.data, cnt.ctypes.data if counters else None))
         return (prim, inst, t, cnt) if counters else (prim, inst, t)

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -86,6 +87,7 @@ typedef LaneHitT<RegCell> LaneHitRegs;  // scenes whose leaf steps are exact tes
 struct LaneCount {
     uint32_t box, tri, sph;
     uint32_t bad;  // COUNT variant only: filter decisions contradicted by the exact test (must stay 0)
+    uint32_t pruned_until, uncertified;  // COUNT variant only: end of the subtree strict pruning would have skipped; ray walked without certificate
 #ifdef RT_TRACE_DIAG  // diagnostic build only (make diag): wave-level step counts and s_memtime cycle stamps
     uint64_t steps, leaf_steps, cyc_wait, cyc_total, lane_steps, exact_box, exact_tri;
 #endif
@@ -133,6 +135,7 @@ RT_DEV GeomS load_geom(cptr<rt_geom> geom, uint32_t p) {
 #define RT_STREAM_REC_SPH2 112u
 #define RT_STREAM_REC_LEAF 48u     /* header + prim0 | prim1 | xform of prim0 | pad: the exact path starts its geometry loads without a detour through rt_node */
 #define RT_STREAM_REC 32u
+#define RT_STREAM_REC_INNER 64u    /* header + local-space box of the subtree (strict pruning, see StrictFilter) + pad */
 #define RT_STREAM_REC_TRI2 144u
 #define RT_STREAM_PAD 384u     /* readable bytes past the last record: the window over-reads */
 #define RT_STREAM_END_NODE 0xFFFFFFu  /* node field of the END record that closes every range (scene array, each instance sub-array) */
@@ -310,6 +313,95 @@ RT_DEV void tri_filter(const TriFilter& f, const Window& w, lanemask& rejA, lane
     rejB = tri_filter_one(sh.y, det.y, ms.y, md.y);
 }
 
+// ---- strict pruning --------------------------------------------------------------------------------------------------
+// The reference descends into every box that passes its WEAK test (three independent per-axis interval tests,
+// bounding_box.rs:27-46): a ray without a hit yet enters every box that lies ahead of it on each axis separately, i.e.
+// most of the tree.  The result, however, is decided by the triangles the reference ACCEPTS, and the walk may skip any
+// subtree that holds none of those (the remaining visits happen in the same order with the same running best, so every
+// accept, every tie and the final hit are unchanged -- DESIGN.md section 5, "Strict pruning", has the argument in full).
+// A subtree is skipped when the ray's LINE certainly misses the box of the subtree's triangles (taken in the
+// triangles' own space, so no transform enters the argument) inflated by tau:
+//   * accepted triangle T, ray (o, d) in T's space  =>  the real point o + T^ d (T^ the exact solution the computed
+//     u, v, t approximate) lies within tau = tau_coef (|o|_inf + radius) of T, PROVIDED the ray is not nearly
+//     parallel to T's plane: |d.n^_T| >= 2^-25 |d|_inf.  (Nearly parallel rays make det tiny against its rounding
+//     error and the reference can then accept garbage; mesh.rs:59 only rejects |det| < 2.2e-16.)
+//   * ray_certified() establishes the proviso for EVERY triangle of the pruned space at once: a direction grid lists,
+//     per cell, the (clustered) unit normals whose perpendicular band meets the cell; the ray checks those in f64.
+//     Rays that fail (about 1 in 2000 on the pagoda) are walked without pruning, as are NaN-capable rays, rays out of
+//     the fp32 range, instance sub-walks and the counting kernel -- which evaluates the prune decision anyway and
+//     counts every accept inside a subtree that pruning would have skipped (cnt.bad, must stay 0).
+// Per axis k the filter evaluates near'_k = min over the two planes of fma32(b', inv', c-) and far'_k = max of
+// fma32(b', inv', c+) with c-/+ = RN32 towards -/+inf of (-o_k inv_k -/+ a_k), a_k = (tau + 2^-22 (B + |o_k|)) |inv_k|
+// (1 + 2^-20): the inflation tau and every fp32 rounding (2^-24 (2 |b inv| + |o inv| + a_k), B >= |b|) are inside
+// a_k, so near'_k <= the real entry parameter of the inflated slab and far'_k >= the real exit.  An accepted triangle
+// implies max_k near'_k <= T^ <= min_k far'_k; the subtree is skipped iff max_k near'_k > min_k far'_k.
+struct StrictFilter { f2 inv_xy, invz_cnx, cn_yz, cp_xy, cpz_; };
+RT_DEV bool strict_filter_init(StrictFilter& f, d3 o, d3 d, const SceneDev& sc) {  // false: this lane must not prune
+    const d3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    const double cx = -(o.x * inv.x), cy = -(o.y * inv.y), cz = -(o.z * inv.z);
+    const double ax = fabs(inv.x), ay = fabs(inv.y), az = fabs(inv.z), ox = fabs(o.x), oy = fabs(o.y), oz = fabs(o.z);
+    const double O = fmax(fmax(ox, oy), oz), B = sc.prune_box_abs_max, I = fmax(fmax(ax, ay), az);
+    const double tau = sc.prune_tau_coef * (O + sc.prune_radius);
+    const double mx = (tau + 0x1p-22 * (B + ox)) * ax * (1.0 + 0x1p-20), my = (tau + 0x1p-22 * (B + oy)) * ay * (1.0 + 0x1p-20),
+                 mz = (tau + 0x1p-22 * (B + oz)) * az * (1.0 + 0x1p-20);
+    const bool ok = fmin(fmin(ax, ay), az) >= 1e-30 && I <= 1e30 && O <= 1e30 && B >= 1e-30 && B <= 1e30 && (B + O) * I <= 1e36 &&
+                    fmax(fmax(mx, my), mz) <= 1e30;   // also false for any NaN
+    f.inv_xy = (f2){(float)inv.x, (float)inv.y};
+    f.invz_cnx = (f2){(float)inv.z, f32_below(cx - mx)};
+    f.cn_yz = (f2){f32_below(cy - my), f32_below(cz - mz)};
+    f.cp_xy = (f2){f32_above(cx + mx), f32_above(cy + my)};
+    f.cpz_ = (f2){f32_above(cz + mz), 0.f};
+    return ok;
+}
+template <int B>  // B: first dword of the record's LOCAL box inside the window; returns the lanes whose line misses it
+RT_DEV lanemask strict_filter(const StrictFilter& f, const Window& w) {
+    f2 nx, ny, nz, fx, fy, fz;
+    PK_FMA_BB(nx, wpair<B + 0>(w), f.inv_xy, 0, f.invz_cnx, 1);
+    PK_FMA_BB(ny, wpair<B + 2>(w), f.inv_xy, 1, f.cn_yz, 0);
+    PK_FMA_BB(nz, wpair<B + 4>(w), f.invz_cnx, 0, f.cn_yz, 1);
+    PK_FMA_BB(fx, wpair<B + 0>(w), f.inv_xy, 0, f.cp_xy, 0);
+    PK_FMA_BB(fy, wpair<B + 2>(w), f.inv_xy, 1, f.cp_xy, 1);
+    PK_FMA_BB(fz, wpair<B + 4>(w), f.invz_cnx, 0, f.cpz_, 0);
+    float n0, n1, n2, f0, f1, f2v;
+    lanemask m;
+    asm("v_min_f32 %[n0], %[nxa], %[nxb]\n\tv_max_f32 %[f0], %[fxa], %[fxb]\n\t"
+        "v_min_f32 %[n1], %[nya], %[nyb]\n\tv_max_f32 %[f1], %[fya], %[fyb]\n\t"
+        "v_min_f32 %[n2], %[nza], %[nzb]\n\tv_max_f32 %[f2], %[fza], %[fzb]\n\t"
+        "v_max3_f32 %[n0], %[n0], %[n1], %[n2]\n\t"
+        "v_min3_f32 %[f0], %[f0], %[f1], %[f2]\n\t"
+        "v_cmp_gt_f32_e64 %[m], %[n0], %[f0]"
+        : [n0] "=&v"(n0), [n1] "=&v"(n1), [n2] "=&v"(n2), [f0] "=&v"(f0), [f1] "=&v"(f1), [f2] "=&v"(f2v), [m] "=&s"(m)
+        : [nxa] "v"(nx.x), [nxb] "v"(nx.y), [nya] "v"(ny.x), [nyb] "v"(ny.y), [nza] "v"(nz.x), [nzb] "v"(nz.y),
+          [fxa] "v"(fx.x), [fxb] "v"(fx.y), [fya] "v"(fy.x), [fyb] "v"(fy.y), [fza] "v"(fz.x), [fzb] "v"(fz.y));
+    return m;
+}
+// Is the direction (in the pruned space) at least 2^-24 |d|_inf away from perpendicular to every triangle normal of that
+// space?  Cell of the folded cube map, then an exact f64 check of the normals listed for it (host side: cert_raster).
+#define RT_CERT_K 512u
+#define RT_CERT_EPS 0x1p-24
+RT_DEV bool ray_certified(const SceneDev& sc, d3 d) {
+    const double ax = fabs(d.x), ay = fabs(d.y), az = fabs(d.z);
+    const double D = fmax(fmax(ax, ay), az);
+    if (!(D >= 0x1p-100 && D <= 0x1p100)) return false;  // also NaN
+    const int a = ax >= ay ? (ax >= az ? 0 : 2) : (ay >= az ? 1 : 2);
+    const double da = a == 0 ? d.x : a == 1 ? d.y : d.z, db = a == 0 ? d.y : a == 1 ? d.z : d.x, dc = a == 0 ? d.z : a == 1 ? d.x : d.y;
+    const double u = db / da, v = dc / da;
+    const double kk = (double)RT_CERT_K * 0.5, top = (double)(RT_CERT_K - 1u);
+    const uint32_t iu = (uint32_t)fmin(fmax(floor((u + 1.0) * kk), 0.0), top), iv = (uint32_t)fmin(fmax(floor((v + 1.0) * kk), 0.0), top);
+    const uint32_t cell = ((uint32_t)a * RT_CERT_K + iv) * RT_CERT_K + iu;
+    const uint32_t* __restrict__ cells = sc.cert_cells;
+    const uint32_t* __restrict__ entries = sc.cert_entries;
+    const double* __restrict__ normals = sc.cert_normals;
+    const uint32_t end = cells[cell + 1];
+    const double thr = RT_CERT_EPS * D;
+    bool ok = true;
+    for (uint32_t e = cells[cell]; e < end; ++e) {
+        const double* n = normals + 3u * (size_t)entries[e];
+        ok = ok & (fabs(d.x * n[0] + d.y * n[1] + d.z * n[2]) >= thr);
+    }
+    return ok;
+}
+
 struct RayS { d3 o, d; double time; };  // ray as handed to this traversal level
 // Where a traversal level gets its f64 ray from.  Only the fp32 filter state is live across the hot loop; the exact
 // paths (a few percent of the steps) fetch the f64 ray again instead of holding 14 VGPRs per lane for it:
@@ -416,10 +508,11 @@ RT_DEV bool box_exact(cptr<rt_node> nodes, uint32_t rec, d3 o, d3 d, double t_mi
            box_axis(nd.bmin[2], nd.bmax[2], o.z, inv.z, t_min, best);
 }
 
-// One record's box test for the wave: returns the mask of lanes that pass and moves the lanes that fail to skip(record).
+// One record's box test for the wave: returns the mask of lanes that descend and moves the others to skip(record).
+// `strict` (wave-uniform): the record is an inner one, whose local box may prune (StrictFilter).
 template <int B, int MODE, bool COUNT, class RAYSRC, class HIT>
-RT_DEV lanemask box_step(const Window& w, const BoxFilter& bf, uint32_t off, uint32_t& wait, uint32_t rec, cptr<rt_node> nodes, const RAYSRC& src, HIT& h,
-                         double t_min, LaneCount& cnt) {
+RT_DEV lanemask box_step(const Window& w, const BoxFilter& bf, const StrictFilter& sf, lanemask sp_enable, bool strict, uint32_t off, uint32_t& wait, uint32_t rec,
+                         cptr<rt_node> nodes, const RAYSRC& src, HIT& h, double t_min, LaneCount& cnt) {
     const lanemask m_act = mask_reached(off, wait);
 #ifdef RT_TRACE_DIAG
     cnt.lane_steps += mask_lane(m_act) ? 1u : 0u;
@@ -427,15 +520,20 @@ RT_DEV lanemask box_step(const Window& w, const BoxFilter& bf, uint32_t off, uin
     if (COUNT) cnt.box += (mask_lane(m_act) && !(rec & RT_NODE_NO_BOX)) ? 1u : 0u;
     lanemask m_pass;
     if (MODE == BOX_PLAIN) {
-        lanemask cp, cf;
+        lanemask cp, cf, sp = 0ull;
         box_filter<B>(bf, w, cp, cf);
-        m_pass = m_act & cp;
-        if (COUNT || (m_act & ~(cp | cf)) != 0ull) {  // rare: a plane value within the error bound of best / t_min
+        if (strict && sp_enable != 0ull) sp = strict_filter<B + 8>(sf, w) & sp_enable;
+        const lanemask sp_apply = COUNT ? 0ull : sp;  // the counting kernel walks the reference's own visited set
+        m_pass = m_act & cp & ~sp_apply;
+        if (COUNT || (m_act & ~(cp | cf | sp_apply)) != 0ull) {  // rare: a plane value within the error bound of best / t_min
             const RayS ray = src.get();
             const bool act = mask_lane(m_act);
             const bool ex = act & box_exact<true>(nodes, rec, ray.o, ray.d, t_min, h.best);
-            if (COUNT) cnt.bad += (act & ((mask_lane(cp) & !ex) | (mask_lane(cf) & ex))) ? 1u : 0u;
-            m_pass = __builtin_amdgcn_ballot_w64(ex);
+            if (COUNT) {
+                cnt.bad += (act & ((mask_lane(cp) & !ex) | (mask_lane(cf) & ex))) ? 1u : 0u;
+                if (ex && mask_lane(sp) && off >= cnt.pruned_until) cnt.pruned_until = wword<B + 6>(w);  // pruning would skip up to here
+            }
+            m_pass = __builtin_amdgcn_ballot_w64(ex) & ~sp_apply;
 #ifdef RT_TRACE_DIAG
             cnt.exact_box += 1;
 #endif
@@ -451,7 +549,7 @@ RT_DEV lanemask box_step(const Window& w, const BoxFilter& bf, uint32_t off, uin
 // Exact f64 tests of a TRI2 leaf for the lanes of m_pass the filter did not reject (COUNT: for every lane of m_pass),
 // one triangle at a time (register pressure); the f64 ray is re-derived here rather than kept live across the hot loop.
 template <bool COUNT, int MODE, class RAYSRC, class HIT>
-RT_DEV void tri2_exact(const SceneDev& sc, uint32_t node, lanemask m_pass, lanemask rejA, lanemask rejB, const RAYSRC& src, uint32_t cur_xf, HIT& h,
+RT_DEV void tri2_exact(const SceneDev& sc, uint32_t node, uint32_t rec_off, lanemask m_pass, lanemask rejA, lanemask rejB, const RAYSRC& src, uint32_t cur_xf, HIT& h,
                        double t_min, uint32_t inst_prim, BoxFilter& bf, LaneCount& cnt) {
     cptr<rt_node> nodes = as_const(sc.nodes);
     cptr<rt_geom> geom = as_const(sc.geom);
@@ -474,7 +572,8 @@ RT_DEV void tri2_exact(const SceneDev& sc, uint32_t node, lanemask m_pass, lanem
         const bool go = pass & (COUNT ? true : !rej) & tri_stage_a(v0, e1, e2, xo, xd, st);
         if (go && tri_hit_tail(st, v0, e1, e2, xo, xd, t_min, h.best, t)) {
             h.best = t; h.prim = p; h.inst = inst_prim; changed = true;
-            if (COUNT) cnt.bad += rej ? 1u : 0u;  // a filtered lane must be one the reference rejects
+            // a filtered lane must be one the reference rejects, and an accept must not lie in a subtree pruning would skip
+            if (COUNT) cnt.bad += (rej || rec_off < cnt.pruned_until) ? 1u : 0u;
         }
     }
     if (MODE == BOX_PLAIN && changed) box_filter_set_best(bf, h.best);
@@ -487,7 +586,19 @@ template <int LEVEL, bool COUNT, bool INST, int MODE, class RAYSRC, class HIT>
 RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src, HIT& h, bool active, double t_min,
                           uint32_t inst_prim, LaneCount& cnt) {
     uint32_t wait = active ? first : 0xFFFFFFFFu;
-    uint32_t off = first, cur_xf = RT_NONE;
+    // strict pruning: top-level walks of NaN-free rays in scenes that have a pruned space; the walk starts in that space
+    const bool prune = LEVEL == 0 && MODE == BOX_PLAIN && sc.prune_on != 0u;
+    uint32_t off = first, cur_xf = prune ? sc.prune_xf : RT_NONE;
+    lanemask clean = 0ull;
+    if (prune) {
+        const RayS ray = src.get();
+        d3 xo, xd;
+        apply_xform(sc, sc.prune_xf, ray, xo, xd);
+        const bool c = active && ray_certified(sc, xd);
+        if (COUNT) cnt.uncertified += (active && !c) ? 1u : 0u;
+        clean = __builtin_amdgcn_ballot_w64(c);
+        RT_RECONVERGE();
+    }
     const uint64_t base = (uint64_t)sc.stream;
     cptr<rt_node> nodes = as_const(sc.nodes);
     cptr<rt_geom> geom = as_const(sc.geom);
@@ -498,11 +609,19 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
     }
     for (;;) {  // one round per transform the walk has to enter; the END record of the range leaves both loops
         TriFilter tf;
+        StrictFilter sf;
+        lanemask sp_enable = 0ull;
         {
             const RayS ray = src.get();
             d3 xo, xd;
             apply_xform(sc, cur_xf, ray, xo, xd);
             tri_filter_init(tf, xo, xd);
+            if (prune && cur_xf == sc.prune_xf) {  // inner records carry boxes of THIS space only
+                const bool ok = strict_filter_init(sf, xo, xd, sc);
+                sp_enable = clean & __builtin_amdgcn_ballot_w64(ok);
+            } else {
+                sf.inv_xy = sf.invz_cnx = sf.cn_yz = sf.cp_xy = sf.cpz_ = (f2){0.f, 0.f};
+            }
         }
         uint32_t want = cur_xf;
         for (;;) {
@@ -510,7 +629,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
 #ifdef RT_TRACE_DIAG
             const uint64_t c0 = __builtin_readcyclecounter();
 #endif
-            if (INST) off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);  // the nested walk makes the compiler class the (wave-uniform) cursor divergent
+            off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);  // the nested walk / the per-lane certificate loop make the compiler class the (wave-uniform) cursor divergent
             window_issue(w, base, off);
             window_wait(w);
             const uint32_t skip = wword<6>(w), rec = wword<7>(w);
@@ -527,27 +646,27 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
                 lanemask rejA, rejB;
                 tri_filter(tf, w, rejA, rejB);
                 if ((m_act & ~(rejA & rejB)) != 0ull) {
-                    const lanemask m_pass = box_step<0, MODE, COUNT>(w, bf, off, wait, rec, nodes, src, h, t_min, cnt);
-                    if ((m_pass & ~(rejA & rejB)) != 0ull) tri2_exact<COUNT, MODE>(sc, node, m_pass, rejA, rejB, src, cur_xf, h, t_min, inst_prim, bf, cnt);
+                    const lanemask m_pass = box_step<0, MODE, COUNT>(w, bf, sf, 0ull, false, off, wait, rec, nodes, src, h, t_min, cnt);
+                    if ((m_pass & ~(rejA & rejB)) != 0ull) tri2_exact<COUNT, MODE>(sc, node, off, m_pass, rejA, rejB, src, cur_xf, h, t_min, inst_prim, bf, cnt);
                     RT_RECONVERGE();
                 }
                 off += RT_STREAM_REC_TRI2;
                 continue;
             }
-            lanemask m_pass = box_step<0, MODE, COUNT>(w, bf, off, wait, rec, nodes, src, h, t_min, cnt);
+            lanemask m_pass = box_step<0, MODE, COUNT>(w, bf, sf, sp_enable, (rec & RT_STREAM_KIND) == RT_STREAM_INNER, off, wait, rec, nodes, src, h, t_min, cnt);
             if (m_pass == 0ull) {
                 off = skip;
             } else if ((rec & RT_STREAM_KIND) == RT_STREAM_INNER) {
-                off += RT_STREAM_REC;
+                off += RT_STREAM_REC_INNER;
                 // the window already holds the next record's header: if that is an inner node too, take it in the same step
-                // (no load, no wait, no trip round the loop) -- a quarter of all steps on the pagoda
-                const uint32_t rec2 = wword<15>(w);
+                // (no load, no wait, no trip round the loop) -- a quarter of all steps on the pagoda before strict pruning
+                const uint32_t rec2 = wword<23>(w);
                 if ((rec2 & RT_STREAM_KIND) == RT_STREAM_INNER) {
 #ifdef RT_TRACE_DIAG
                     cnt.steps += 1;
 #endif
-                    m_pass = box_step<8, MODE, COUNT>(w, bf, off, wait, rec2, nodes, src, h, t_min, cnt);
-                    off = m_pass == 0ull ? wword<14>(w) : off + RT_STREAM_REC;
+                    m_pass = box_step<16, MODE, COUNT>(w, bf, sf, sp_enable, true, off, wait, rec2, nodes, src, h, t_min, cnt);
+                    off = m_pass == 0ull ? wword<22>(w) : off + RT_STREAM_REC_INNER;
                 }
             } else if ((rec & RT_STREAM_KIND) == RT_STREAM_SPH2) {  // one or two spheres: exact f64 test (shape.rs:93-121) on inline geometry
                 if (wword<8>(w) != cur_xf) {
@@ -590,7 +709,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
                 lanemask rejA, rejB;
                 tri_filter(tf, w, rejA, rejB);
                 if (COUNT || (m_pass & ~(rejA & rejB)) != 0ull) {  // rare: most tested triangles are nowhere near the rays
-                    tri2_exact<COUNT, MODE>(sc, node, m_pass, rejA, rejB, src, cur_xf, h, t_min, inst_prim, bf, cnt);
+                    tri2_exact<COUNT, MODE>(sc, node, off - RT_STREAM_REC_TRI2, m_pass, rejA, rejB, src, cur_xf, h, t_min, inst_prim, bf, cnt);
                     RT_RECONVERGE();
                 }
             } else {  // any other leaf: exact tests on the blob's tables
@@ -646,7 +765,7 @@ RT_DEV void traverse(const SceneDev& sc, uint32_t first, const RAYSRC& src, HIT&
 }
 
 #ifndef RT_TRACE_WAVES
-#define RT_TRACE_WAVES 6  /* waves per SIMD the register allocator must leave room for */
+#define RT_TRACE_WAVES 5  /* waves per SIMD the register allocator must leave room for */
 #endif
 #ifndef RT_TRACE_WAVES_REGS
 #define RT_TRACE_WAVES_REGS 3
@@ -682,7 +801,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : 
     LaneHit h;
     h.best.p = (lptr<volatile double>)&lds_best[threadIdx.x]; h.prim.p = (lptr<volatile uint32_t>)&lds_prim[threadIdx.x]; h.inst.p = (lptr<volatile uint32_t>)&lds_inst[threadIdx.x];
     h.best = t_max; h.prim = RT_NONE; h.inst = RT_NONE;
-    LaneCount cnt; cnt.box = cnt.tri = cnt.sph = cnt.bad = 0;
+    LaneCount cnt; cnt.box = cnt.tri = cnt.sph = cnt.bad = 0; cnt.pruned_until = 0; cnt.uncertified = 0;
 #ifdef RT_TRACE_DIAG
     cnt.steps = cnt.leaf_steps = cnt.cyc_wait = cnt.lane_steps = cnt.exact_box = cnt.exact_tri = 0; cnt.cyc_total = __builtin_readcyclecounter();
 #endif
@@ -713,7 +832,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : 
     }
     if (COUNT && stats) {
         uint64_t b = wave_sum_u64(cnt.box), t = wave_sum_u64(cnt.tri), s = wave_sum_u64(cnt.sph), bad = wave_sum_u64(cnt.bad);
+        const uint64_t unc = wave_sum_u64(cnt.uncertified);
         if (lane_id() == 0) {
+            atomicAdd(&stats[14], (unsigned long long)unc);
             atomicAdd(&stats[1], (unsigned long long)b); atomicAdd(&stats[2], (unsigned long long)t); atomicAdd(&stats[3], (unsigned long long)s);
             atomicAdd(&stats[13], (unsigned long long)bad);
         }
@@ -1061,6 +1182,9 @@ struct rt_scene {
     uint8_t* d_mat_uses_uv = nullptr;
     uint8_t* d_stream = nullptr;
     uint32_t* d_node_off = nullptr;
+    uint32_t* d_cert_cells = nullptr;
+    uint32_t* d_cert_entries = nullptr;
+    double* d_cert_normals = nullptr;
     SceneDev dev{};
     rt_blob_header hdr{};
     std::vector<rt_prim> host_prims;
@@ -1234,6 +1358,192 @@ static int run_paths(rt_scene* sc, uint32_t n, bool explicit_lists, uint32_t wid
     return RT_OK;
 }
 
+
+// ---- strict pruning: host side -----------------------------------------------------------------------------------------
+// (proof and definitions: DESIGN.md section 5, "Strict pruning"; device side: StrictFilter / ray_certified)
+/* RT_CERT_K (direction grid: 3 folded cube-map faces of K x K cells) and RT_CERT_EPS (a ray is certified against a normal
+ * n^ iff |d.n^| >= EPS |d|_inf) are defined with ray_certified above */
+#define RT_CERT_MAX_NORMALS (1u << 17)
+#define RT_PRUNE_MIN_TRIS 64u
+#define RT_PRUNE_MIN_SHAPE 0x1p-10        /* |e1 x e2|_2 / (|e1|_1 |e2|_1) below this: the triangle is never pruned */
+struct PruneHost {
+    bool on = false;
+    uint32_t xf = RT_NONE;                 // the one transform space whose triangles are pruned
+    double tau_coef = 0.0, radius = 0.0, box_abs_max = 0.0, shape_min = 0.0;
+    uint64_t n_tris = 0, n_prunable_nodes = 0;
+    std::vector<float> local_box;          // 6 per node: (lo, hi) per axis in space xf, (-inf, +inf) = never pruned
+    std::vector<double> normals;           // 3 per distinct (clustered) unit normal
+    std::vector<uint32_t> cell_off, entries;  // CSR: normals whose "nearly perpendicular" band meets the direction cell
+};
+static float f32_up_host(double v) {       // smallest float >= v (NaN / overflow: +inf)
+    if (!(v <= 3.4e38)) return std::numeric_limits<float>::infinity();
+    float f = (float)v;
+    if ((double)f < v) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+    return f;
+}
+static float f32_down_host(double v) { return -f32_up_host(-v); }
+template <class EMIT>
+static void cert_raster(const double* n, EMIT&& emit) {
+    // Face a: directions with |d_a| = |d|_inf, scaled to d_a = 1: (u, v) = (d_b, d_c) / d_a in [-1, 1]^2 and
+    // d.n^ / |d|_inf = +-g(u, v), g = n_a + n_b u + n_c v (gnomonic projection: the great circle is a straight line).
+    // A cell is listed when |g(centre)| <= EPS + (|n_b| + |n_c|)(half cell + 2^-30) + 2^-40: g varies by at most
+    // (|n_b| + |n_c|) half over the cell, the 2^-30 covers the rounding of the cell index computed on the device.
+    const uint32_t K = RT_CERT_K;
+    const double cell = 2.0 / K, half = 1.0 / K;
+    for (int a = 0; a < 3; ++a) {
+        const int b = (a + 1) % 3, c = (a + 2) % 3;
+        const double na = n[a], nb = n[b], nc = n[c];
+        const double thr = RT_CERT_EPS + (std::fabs(nb) + std::fabs(nc)) * (half + 0x1p-30) + 0x1p-40;
+        const bool solve_u = std::fabs(nb) >= std::fabs(nc);  // solve along the axis with the larger coefficient
+        const double ns = solve_u ? nb : nc, nr = solve_u ? nc : nb;
+        for (uint32_t j = 0; j < K; ++j) {
+            const double r = -1.0 + ((double)j + 0.5) * cell;
+            const double k = na + nr * r;
+            int64_t i0 = 0, i1 = (int64_t)K - 1;
+            if (std::fabs(ns) > 1e-9) {
+                double lo = (-thr - k) / ns, hi = (thr - k) / ns;
+                if (lo > hi) std::swap(lo, hi);
+                if (hi < -1.0 - cell || lo > 1.0 + cell) continue;
+                i0 = (int64_t)std::floor((std::max(lo, -1.0 - cell) + 1.0) / cell) - 1;
+                i1 = (int64_t)std::floor((std::min(hi, 1.0 + cell) + 1.0) / cell) + 1;
+                i0 = std::max<int64_t>(i0, 0); i1 = std::min<int64_t>(i1, (int64_t)K - 1);
+            }
+            for (int64_t i = i0; i <= i1; ++i) {
+                const double sc = -1.0 + ((double)i + 0.5) * cell;
+                if (std::fabs(k + ns * sc) > thr * (1.0 + 0x1p-40)) continue;
+                const uint32_t iu = solve_u ? (uint32_t)i : j, iv = solve_u ? j : (uint32_t)i;
+                emit(((uint32_t)a * K + iv) * K + iu);
+            }
+        }
+    }
+}
+template <class IS_TRI2>
+static void build_prune(const rt_blob_header& h, const rt_node* nodes, const rt_geom* geom, IS_TRI2&& is_tri2, PruneHost& R) {
+    const float inf = std::numeric_limits<float>::infinity();
+    R.local_box.assign((size_t)h.n_nodes * 6, 0.f);
+    for (size_t i = 0; i < (size_t)h.n_nodes; ++i)
+        for (int k = 0; k < 3; ++k) { R.local_box[i * 6 + 2 * k] = -inf; R.local_box[i * 6 + 2 * k + 1] = inf; }
+    if (h.root_end <= h.root_node) return;
+    {   // skip ranges of the scene-level array must nest (they do for any tree; a blob is only validated for forward links)
+        std::vector<uint32_t> open;
+        for (uint32_t i = h.root_node; i < h.root_end; ++i) {
+            while (!open.empty() && open.back() <= i) open.pop_back();
+            if (!open.empty() && nodes[i].skip > open.back()) return;
+            open.push_back(nodes[i].skip);
+        }
+    }
+    // the space with the most filter-leaf triangles
+    std::vector<std::pair<uint32_t, uint64_t>> per_xf;
+    for (uint32_t i = h.root_node; i < h.root_end; ++i) {
+        if (!is_tri2(nodes[i])) continue;
+        const uint32_t xf = geom[nodes[i].prim0].xform;
+        const uint64_t nt = nodes[i].prim1 != RT_NONE ? 2 : 1;
+        bool found = false;
+        for (auto& e : per_xf) if (e.first == xf) { e.second += nt; found = true; break; }
+        if (!found) { if (per_xf.size() >= 64) continue; per_xf.push_back({xf, nt}); }
+    }
+    uint64_t best = 0;
+    for (auto& e : per_xf) if (e.second > best) { best = e.second; R.xf = e.first; }
+    if (best < RT_PRUNE_MIN_TRIS) return;
+    // per leaf: are all its triangles well-shaped, and the box of their vertices in their own space
+    const uint32_t n0 = h.root_node, n1 = h.root_end;
+    std::vector<uint8_t> ok((size_t)(n1 - n0), 0);
+    std::vector<double> box((size_t)(n1 - n0) * 6);
+    double shape_min = 1.0, e_max = 0.0, v_max = 0.0;
+    struct Key { int64_t k[3]; bool operator<(const Key& o) const { return std::lexicographical_compare(k, k + 3, o.k, o.k + 3); } };
+    std::vector<std::pair<Key, std::array<double, 3>>> keyed;
+    for (uint32_t i = n0; i < n1; ++i) {
+        const rt_node& nd = nodes[i];
+        if (!is_tri2(nd) || geom[nd.prim0].xform != R.xf) continue;
+        bool good = true;
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        std::array<double, 3> nh[2]; int nn = 0;
+        double smin = 1.0, emax = 0.0, vmax = 0.0;
+        for (uint32_t p : {nd.prim0, nd.prim1}) {
+            if (p == RT_NONE) continue;
+            const double* v0 = geom[p].d; const double* e1 = geom[p].d + 3; const double* e2 = geom[p].d + 6;
+            for (int k = 0; k < 9; ++k) good = good && std::isfinite(geom[p].d[k]);
+            const double E1 = std::fabs(e1[0]) + std::fabs(e1[1]) + std::fabs(e1[2]), E2 = std::fabs(e2[0]) + std::fabs(e2[1]) + std::fabs(e2[2]);
+            const double V = std::max(std::max(std::fabs(v0[0]), std::fabs(v0[1])), std::fabs(v0[2]));
+            good = good && E1 >= 0x1p-100 && E1 <= 0x1p100 && E2 >= 0x1p-100 && E2 <= 0x1p100 && V <= 0x1p100;
+            if (!good) break;
+            const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+            const double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            const double shape = len / (E1 * E2);
+            good = good && shape >= RT_PRUNE_MIN_SHAPE * (1.0 + 0x1p-20);
+            if (!good) break;
+            smin = std::min(smin, shape); emax = std::max(emax, std::max(E1, E2)); vmax = std::max(vmax, V);
+            int big = 0;
+            for (int k = 1; k < 3; ++k) if (std::fabs(n[k]) > std::fabs(n[big])) big = k;
+            const double sgn = n[big] < 0.0 ? -1.0 : 1.0;
+            nh[nn++] = {sgn * n[0] / len, sgn * n[1] / len, sgn * n[2] / len};
+            for (int k = 0; k < 3; ++k) {   // vertices v0, v0 + e1, v0 + e2 (sums rounded outward)
+                const double a = v0[k] + e1[k], c = v0[k] + e2[k];
+                lo[k] = std::min(lo[k], std::min(v0[k], std::min(std::nextafter(a, -INFINITY), std::nextafter(c, -INFINITY))));
+                hi[k] = std::max(hi[k], std::max(v0[k], std::max(std::nextafter(a, INFINITY), std::nextafter(c, INFINITY))));
+            }
+        }
+        if (!good) continue;
+        ok[i - n0] = 1;
+        for (int k = 0; k < 3; ++k) { box[(size_t)(i - n0) * 6 + 2 * k] = lo[k]; box[(size_t)(i - n0) * 6 + 2 * k + 1] = hi[k]; }
+        shape_min = std::min(shape_min, smin); e_max = std::max(e_max, emax); v_max = std::max(v_max, vmax);
+        R.n_tris += (uint64_t)nn;
+        for (int t = 0; t < nn; ++t) {
+            Key key;
+            for (int k = 0; k < 3; ++k) key.k[k] = (int64_t)std::llround(nh[t][k] * 0x1p34);
+            keyed.push_back({key, nh[t]});
+        }
+    }
+    // inner nodes, bottom-up: prunable iff every leaf below is a good leaf of the space (children: i+1, skip(i+1), ...)
+    for (uint32_t i = n1; i-- > n0;) {
+        const rt_node& nd = nodes[i];
+        if (nd.prim0 != RT_NONE) continue;
+        bool good = nd.skip > i + 1;
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t c = i + 1; good && c < nd.skip; c = nodes[c].skip) {
+            good = ok[c - n0] != 0;
+            for (int k = 0; k < 3 && good; ++k) { lo[k] = std::min(lo[k], box[(size_t)(c - n0) * 6 + 2 * k]); hi[k] = std::max(hi[k], box[(size_t)(c - n0) * 6 + 2 * k + 1]); }
+        }
+        if (!good) continue;
+        ok[i - n0] = 1;
+        for (int k = 0; k < 3; ++k) { box[(size_t)(i - n0) * 6 + 2 * k] = lo[k]; box[(size_t)(i - n0) * 6 + 2 * k + 1] = hi[k]; }
+    }
+    double babs = 0.0;
+    for (uint32_t i = n0; i < n1; ++i) {
+        if (!ok[i - n0] || nodes[i].prim0 != RT_NONE) continue;   // only inner records carry a local box
+        ++R.n_prunable_nodes;
+        for (int k = 0; k < 3; ++k) {
+            const double lo = box[(size_t)(i - n0) * 6 + 2 * k], hi = box[(size_t)(i - n0) * 6 + 2 * k + 1];
+            R.local_box[(size_t)i * 6 + 2 * k] = f32_down_host(lo); R.local_box[(size_t)i * 6 + 2 * k + 1] = f32_up_host(hi);
+            babs = std::max(babs, std::max(std::fabs(lo), std::fabs(hi)));
+        }
+    }
+    if (R.n_prunable_nodes == 0 || keyed.empty()) return;
+    // distinct normals: members of a cluster differ from its representative by < 2^-33 per component
+    std::sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    for (size_t i = 0; i < keyed.size(); ++i)
+        if (i == 0 || keyed[i - 1].first < keyed[i].first) { R.normals.push_back(keyed[i].second[0]); R.normals.push_back(keyed[i].second[1]); R.normals.push_back(keyed[i].second[2]); }
+    const size_t M = R.normals.size() / 3;
+    if (M > RT_CERT_MAX_NORMALS) { R.normals.clear(); return; }
+    const size_t ncell = 3u * (size_t)RT_CERT_K * RT_CERT_K;
+    R.cell_off.assign(ncell + 1, 0);
+    for (size_t m = 0; m < M; ++m) cert_raster(&R.normals[3 * m], [&](uint32_t c) { ++R.cell_off[c + 1]; });
+    for (size_t c = 0; c < ncell; ++c) R.cell_off[c + 1] += R.cell_off[c];
+    if (R.cell_off[ncell] > 0x7FFFFFFFu) { R.normals.clear(); R.cell_off.clear(); return; }
+    R.entries.assign(R.cell_off[ncell], 0);
+    {
+        std::vector<uint32_t> fill(R.cell_off.begin(), R.cell_off.end() - 1);
+        for (size_t m = 0; m < M; ++m) cert_raster(&R.normals[3 * m], [&](uint32_t c) { R.entries[fill[c]++] = (uint32_t)m; });
+    }
+    // tau = tau_coef (|o|_inf + radius) bounds the distance between the ray point the reference accepts and the triangle
+    R.shape_min = shape_min;
+    R.tau_coef = 0x1p-21 / shape_min;
+    R.radius = v_max + e_max;
+    R.box_abs_max = babs;
+    R.on = true;
+}
+
+
 extern "C" {
 
 const char* rt_last_error(void) { return g_err.c_str(); }
@@ -1281,6 +1591,7 @@ static bool range_ok(uint64_t off, uint64_t count, uint64_t elem, uint64_t total
     return off % 16 == 0 && off <= total && count * elem <= total - off;
 }
 
+
 // Everything rt_scene_upload derives from a blob without touching the device: validation of every index the kernels
 // follow, and the trace stream.  Also behind rt_stream_build_host, so the CPU-only tests can check the stream.
 struct ScenePrep {
@@ -1290,6 +1601,7 @@ struct ScenePrep {
     std::vector<uint32_t> rec_off, end_off;
     double box_abs_max = 0.0;
     uint32_t root_off = 0;
+    PruneHost prune;
 };
 static int prepare_scene(const void* blob, uint64_t nbytes, ScenePrep& P) {
     if (nbytes < sizeof(rt_blob_header)) return fail(RT_ERR_BAD_BLOB, "blob smaller than its header");
@@ -1380,6 +1692,7 @@ static int prepare_scene(const void* blob, uint64_t nbytes, ScenePrep& P) {
         if (nd.prim0 == RT_NONE || geom[nd.prim0].kind != RT_PRIM_SPHERE) return false;
         return nd.prim1 == RT_NONE || (geom[nd.prim1].kind == RT_PRIM_SPHERE && geom[nd.prim0].xform == geom[nd.prim1].xform);
     };
+    build_prune(h, nodes, geom, is_tri2, P.prune);
     // ranges: the scene-level array and every instance sub-array (validated above: disjoint, links stay inside);
     // range_end[i] = end index of the range node i belongs to, ends_here[e] = some range ends before node e
     std::vector<uint32_t> range_end((size_t)h.n_nodes, h.n_nodes);
@@ -1397,7 +1710,7 @@ static int prepare_scene(const void* blob, uint64_t nbytes, ScenePrep& P) {
     for (uint32_t i = 0; i <= h.n_nodes; ++i) {
         if (ends_here[i]) { end_off[i] = (uint32_t)stream_bytes; stream_bytes += RT_STREAM_REC; }  // END record of the range(s) ending here
         rec_off[i] = (uint32_t)stream_bytes;
-        if (i < h.n_nodes) stream_bytes += is_tri2(nodes[i]) ? RT_STREAM_REC_TRI2 : is_sph2(nodes[i]) ? RT_STREAM_REC_SPH2 : nodes[i].prim0 != RT_NONE ? RT_STREAM_REC_LEAF : RT_STREAM_REC;
+        if (i < h.n_nodes) stream_bytes += is_tri2(nodes[i]) ? RT_STREAM_REC_TRI2 : is_sph2(nodes[i]) ? RT_STREAM_REC_SPH2 : nodes[i].prim0 != RT_NONE ? RT_STREAM_REC_LEAF : RT_STREAM_REC_INNER;
         if (stream_bytes + RT_STREAM_PAD > 0xFFFFFFF0ull) { return fail(RT_ERR_UNSUPPORTED, "trace stream larger than 4 GiB"); }
     }
     // a link to the end of the node's own range lands on that range's END record
@@ -1424,7 +1737,7 @@ static int prepare_scene(const void* blob, uint64_t nbytes, ScenePrep& P) {
         const bool nb = (nd.flags & RT_NODE_NO_BOX) != 0, tri2 = is_tri2(nd), sph2 = is_sph2(nd);
         uint32_t fl = nd.flags & (RT_NODE_NO_BOX | RT_NODE_DUP_RIGHT);
         fl |= tri2 ? RT_STREAM_TRI2 : sph2 ? RT_STREAM_SPH2 : nd.prim0 != RT_NONE ? RT_STREAM_LEAF : RT_STREAM_INNER;
-        const uint32_t rec_bytes = tri2 ? RT_STREAM_REC_TRI2 : sph2 ? RT_STREAM_REC_SPH2 : nd.prim0 != RT_NONE ? RT_STREAM_REC_LEAF : RT_STREAM_REC;
+        const uint32_t rec_bytes = tri2 ? RT_STREAM_REC_TRI2 : sph2 ? RT_STREAM_REC_SPH2 : nd.prim0 != RT_NONE ? RT_STREAM_REC_LEAF : RT_STREAM_REC_INNER;
         float box[6];
         for (int k = 0; k < 3; ++k) {  // list items have no box in the reference: see the box filter
             box[2 * k] = nb ? -std::numeric_limits<float>::infinity() : (float)nd.bmin[k];
@@ -1433,6 +1746,7 @@ static int prepare_scene(const void* blob, uint64_t nbytes, ScenePrep& P) {
         }
         const uint32_t words[2] = {link_off(i, nd.skip), fl | ((rec_bytes / 16u) << 4) | (i << 8)};
         memcpy(rec, box, 24); memcpy(rec + 24, words, 8);
+        if (nd.prim0 == RT_NONE) memcpy(rec + RT_STREAM_REC, &P.prune.local_box[(size_t)i * 6], 24);  // inner: box of the subtree's triangles in their own space
         if (!tri2 && !sph2 && nd.prim0 != RT_NONE) {
             const uint32_t ids[4] = {nd.prim0, nd.prim1, geom[nd.prim0].xform, 0u};
             memcpy(rec + RT_STREAM_REC, ids, 16);
@@ -1518,11 +1832,23 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     if (e == hipSuccess) e = hipMemcpy(sc->d_node_off, rec_off.data(), rec_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(sc->dblob, blob, nbytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(sc->d_mat_uses_uv, uses_uv.data(), uses_uv.size(), hipMemcpyHostToDevice);
+    const PruneHost& pr = P.prune;
+    if (pr.on) {
+        if (e == hipSuccess) e = hipMalloc((void**)&sc->d_cert_cells, pr.cell_off.size() * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemcpy(sc->d_cert_cells, pr.cell_off.data(), pr.cell_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void**)&sc->d_cert_entries, std::max<size_t>(pr.entries.size(), 1) * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemcpy(sc->d_cert_entries, pr.entries.data(), pr.entries.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void**)&sc->d_cert_normals, pr.normals.size() * sizeof(double));
+        if (e == hipSuccess) e = hipMemcpy(sc->d_cert_normals, pr.normals.data(), pr.normals.size() * sizeof(double), hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) {
         if (sc->dblob) (void)hipFree(sc->dblob);
         if (sc->d_mat_uses_uv) (void)hipFree(sc->d_mat_uses_uv);
         if (sc->d_stream) (void)hipFree(sc->d_stream);
         if (sc->d_node_off) (void)hipFree(sc->d_node_off);
+        if (sc->d_cert_cells) (void)hipFree(sc->d_cert_cells);
+        if (sc->d_cert_entries) (void)hipFree(sc->d_cert_entries);
+        if (sc->d_cert_normals) (void)hipFree(sc->d_cert_normals);
         delete sc;
         return fail(e == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, hipGetErrorString(e));
     }
@@ -1536,6 +1862,9 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     v.mat_uses_uv = sc->d_mat_uses_uv;
     v.stream = sc->d_stream; v.root_off = P.root_off;
     v.node_off = sc->d_node_off; v.box_abs_max = box_abs_max;
+    v.cert_cells = sc->d_cert_cells; v.cert_entries = sc->d_cert_entries; v.cert_normals = sc->d_cert_normals;
+    v.prune_on = pr.on ? 1u : 0u; v.prune_xf = pr.xf;
+    v.prune_tau_coef = pr.tau_coef; v.prune_radius = pr.radius; v.prune_box_abs_max = pr.box_abs_max;
     v.n_nodes = h.n_nodes; v.boxes_finite = boxes_finite ? 1u : 0u;
     v.camera = h.camera; v.n_lights = h.n_lights; v.root_node = h.root_node; v.root_end = h.root_end; v.background = h.background;
     {   // ray-sorting grid: mean +- 2.5 sigma of the scene-level leaf-box centres (robust against a 1000-unit ground sphere
@@ -1573,6 +1902,9 @@ int rt_scene_destroy(rt_scene* sc) {
     (void)hipFree(sc->d_mat_uses_uv);
     (void)hipFree(sc->d_stream);
     (void)hipFree(sc->d_node_off);
+    if (sc->d_cert_cells) (void)hipFree(sc->d_cert_cells);
+    if (sc->d_cert_entries) (void)hipFree(sc->d_cert_entries);
+    if (sc->d_cert_normals) (void)hipFree(sc->d_cert_normals);
     delete sc;
     return RT_OK;
 }
@@ -1593,7 +1925,7 @@ int rt_trace_closest_device(rt_scene* sc, uint32_t n, const double* rays_dev, do
 int rt_trace_closest(rt_scene* sc, uint32_t n, const double* rays, double t_min, double t_max, uint32_t* prim_id, uint32_t* inst_id, double* t,
                      uint64_t* counters) {
     if (!sc || (n && (!rays || !prim_id || !t))) return fail(RT_ERR_BAD_ARG, "rt_trace_closest: null argument");
-    if (n == 0) { if (counters) counters[0] = counters[1] = counters[2] = counters[3] = 0; return RT_OK; }
+    if (n == 0) { if (counters) for (int k = 0; k < 8; ++k) counters[k] = 0; return RT_OK; }
     HIP_OK(hipSetDevice(sc->ctx->device));
     int rc = ws_ensure(sc, n, sc->ws.depth > 0 ? sc->ws.depth : 1);
     if (rc != RT_OK) return rc;
@@ -1619,7 +1951,7 @@ int rt_trace_closest(rt_scene* sc, uint32_t n, const double* rays, double t_min,
         prim_id[i] = p.object_id;
         if (inst_id) inst_id[i] = hi[i] != RT_NONE ? sc->host_prims[hi[i]].inst_id : p.inst_id;
     }
-    if (counters) { counters[0] = st4[1]; counters[1] = st4[2]; counters[2] = st4[3]; counters[3] = st4[13]; }
+    if (counters) { counters[0] = st4[1]; counters[1] = st4[2]; counters[2] = st4[3]; counters[3] = st4[13]; counters[4] = st4[14]; counters[5] = counters[6] = counters[7] = 0; }
     return RT_OK;
 }
 

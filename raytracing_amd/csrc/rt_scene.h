@@ -29,6 +29,12 @@ struct SceneDev {
     const uint8_t* stream;  // trace stream (rt_device.hip): fp32 filter records in pre-order
     const uint32_t* node_off;  // [n_nodes + 1] byte offset of each node's record in `stream`
     double box_abs_max;        // max |coordinate| over the finite boxes (box filter error bound)
+    // strict pruning (rt_device.hip, StrictFilter / ray_certified): one transform space, its direction grid and error constants
+    const uint32_t* cert_cells;    // [3 K K + 1] CSR offsets into cert_entries
+    const uint32_t* cert_entries;  // indices into cert_normals
+    const double* cert_normals;    // 3 per distinct unit normal of the pruned space
+    double prune_tau_coef, prune_radius, prune_box_abs_max;
+    uint32_t prune_on, prune_xf;
     uint32_t root_off;  // first scene-level record in `stream` (the range is closed by an END record)
     rt_camera camera;
     uint32_t n_lights, root_node, root_end, background;

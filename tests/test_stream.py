@@ -17,7 +17,7 @@ from scene_text import SceneText, scale, translate
 
 NO_BOX, DUP_RIGHT = 1, 2
 INNER, TRI2, LEAF, SPH2 = 0, 4, 8, 12
-REC_BYTES = {INNER: 32, TRI2: 144, LEAF: 48, SPH2: 112}
+REC_BYTES = {INNER: 64, TRI2: 144, LEAF: 48, SPH2: 112}
 END_NODE = 0xFFFFFF
 PAD = 384
 SCENES = ["random", "cornell", "simple", "simple_triangle", "mesh", "simple_light", "sphere", "random_blur"]
