@@ -92,6 +92,19 @@ class HostScene:
         _hip_check(_ffi.hip().rt_stream_build_host(b, len(b), out.ctypes.data, out.nbytes, C.byref(n), C.byref(root), off.ctypes.data))
         return out, int(root.value), off
 
+    def prune_info(self, rays=None):
+        """Strict-pruning set-up of this scene as rt_scene_upload derives it (host only).  rays: n x 6 (origin, direction) in the
+        pruned space -> also returns which of them the device certifies for pruning."""
+        b = self.blob()
+        info = np.zeros(12)
+        n = 0 if rays is None else len(rays)
+        r = np.ascontiguousarray(rays, np.float64) if n else np.zeros((1, 6))
+        cert = np.zeros(max(n, 1), np.uint8)
+        _hip_check(_ffi.hip().rt_prune_info_host(b, len(b), info.ctypes.data, n, r.ctypes.data, cert.ctypes.data))
+        keys = ("on", "xform", "triangles", "prunable_nodes", "normals", "grid_entries", "shape_min", "tau_coef", "delta_coef", "radius", "box_abs_max")
+        d = dict(zip(keys, info))
+        return (d, cert[:n].astype(bool)) if rays is not None else d
+
     def __del__(self):
         try:
             if self._h:

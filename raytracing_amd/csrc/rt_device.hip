@@ -90,6 +90,7 @@ struct LaneCount {
     uint32_t pruned_until, uncertified;  // COUNT variant only: end of the subtree strict pruning would have skipped; ray walked without certificate
 #ifdef RT_TRACE_DIAG  // diagnostic build only (make diag): wave-level step counts and s_memtime cycle stamps
     uint64_t steps, leaf_steps, cyc_wait, cyc_total, lane_steps, exact_box, exact_tri;
+    uint32_t diag_flags;  // bit 0: top-level walk in the NaN-capable (literal) mode, bit 1: ray not certified for pruning, bit 2: fp32 range guard failed
 #endif
 };
 
@@ -379,10 +380,48 @@ RT_DEV lanemask strict_filter(const StrictFilter& f, const Window& w) {
 // space?  Cell of the folded cube map, then an exact f64 check of the normals listed for it (host side: cert_raster).
 #define RT_CERT_K 512u
 #define RT_CERT_EPS 0x1p-24
-RT_DEV bool ray_certified(const SceneDev& sc, d3 d) {
+struct CertEntry { float nx, ny, nz; uint32_t cluster; };  // a listed normal (fp32 copy for the first look) and its cluster
+// A ray that is nearly parallel to a triangle's plane AND starts within delta of that plane is "suspect" for the
+// triangle's leaf: the reference may accept garbage there, so subtrees holding that leaf are never pruned for this ray.
+#define RT_SUSPECT_SLOTS 3
+struct Suspects {
+    uint32_t leaf[RT_SUSPECT_SLOTS];  // stream offsets of the suspect leaves, 0xFFFFFFFF = unused
+    bool overflow;                    // more suspect leaves than slots: the ray is walked without pruning
+    RT_DEV void add(uint32_t off) {
+        bool placed = false;
+#pragma unroll
+        for (int k = 0; k < RT_SUSPECT_SLOTS; ++k) {
+            if (placed || leaf[k] == off) { placed = true; continue; }
+            if (leaf[k] == 0xFFFFFFFFu) { leaf[k] = off; placed = true; }
+        }
+        overflow = overflow || !placed;
+    }
+};
+// second stage for one listed cluster: exact direction test, then the distance of the origin from the cluster's planes
+RT_DEV void cluster_suspects(const SceneDev& sc, uint32_t c, d3 o, d3 d, double thr, double delta, Suspects& sus) {
+    const double* __restrict__ n = sc.cert_normals + 3u * (size_t)c;
+    if (fabs(d.x * n[0] + d.y * n[1] + d.z * n[2]) >= thr) return;
+    // Nearly parallel to the planes of this cluster.  The reference can only accept such a triangle if the origin
+    // lies within delta of its plane (otherwise one of the u / v numerators exceeds det): collect the leaves of such planes.
+    const double q = o.x * n[0] + o.y * n[1] + o.z * n[2];
+    const double* __restrict__ pl = sc.cert_planes;
+    const uint32_t* __restrict__ leaf = sc.cert_plane_leaf;
+    uint32_t lo = sc.cert_plane_off[c], hi = sc.cert_plane_off[c + 1];
+    const uint32_t last = hi;
+    while (lo < hi) {  // first plane offset >= q - delta
+        const uint32_t mid = (lo + hi) >> 1;
+        if (pl[mid] < q - delta) lo = mid + 1; else hi = mid;
+    }
+    for (; lo < last && !(pl[lo] > q + delta) && !sus.overflow; ++lo) sus.add(leaf[lo]);
+}
+// false: the ray must be walked without pruning
+RT_DEV bool ray_certified(const SceneDev& sc, d3 o, d3 d, Suspects& sus) {
+#pragma unroll
+    for (int k = 0; k < RT_SUSPECT_SLOTS; ++k) sus.leaf[k] = 0xFFFFFFFFu;
+    sus.overflow = false;
     const double ax = fabs(d.x), ay = fabs(d.y), az = fabs(d.z);
-    const double D = fmax(fmax(ax, ay), az);
-    if (!(D >= 0x1p-100 && D <= 0x1p100)) return false;  // also NaN
+    const double D = fmax(fmax(ax, ay), az), O = fmax(fmax(fabs(o.x), fabs(o.y)), fabs(o.z));
+    if (!(D >= 0x1p-100 && D <= 0x1p100 && O <= 0x1p100)) return false;  // also NaN
     const int a = ax >= ay ? (ax >= az ? 0 : 2) : (ay >= az ? 1 : 2);
     const double da = a == 0 ? d.x : a == 1 ? d.y : d.z, db = a == 0 ? d.y : a == 1 ? d.z : d.x, dc = a == 0 ? d.z : a == 1 ? d.x : d.y;
     const double u = db / da, v = dc / da;
@@ -390,17 +429,34 @@ RT_DEV bool ray_certified(const SceneDev& sc, d3 d) {
     const uint32_t iu = (uint32_t)fmin(fmax(floor((u + 1.0) * kk), 0.0), top), iv = (uint32_t)fmin(fmax(floor((v + 1.0) * kk), 0.0), top);
     const uint32_t cell = ((uint32_t)a * RT_CERT_K + iv) * RT_CERT_K + iu;
     const uint32_t* __restrict__ cells = sc.cert_cells;
-    const uint32_t* __restrict__ entries = sc.cert_entries;
-    const double* __restrict__ normals = sc.cert_normals;
-    const uint32_t end = cells[cell + 1];
-    const double thr = RT_CERT_EPS * D;
-    bool ok = true;
-    for (uint32_t e = cells[cell]; e < end; ++e) {
-        const double* n = normals + 3u * (size_t)entries[e];
-        ok = ok & (fabs(d.x * n[0] + d.y * n[1] + d.z * n[2]) >= thr);
+    const float4* __restrict__ entries = (const float4*)sc.cert_entries;
+    const uint32_t beg = cells[cell], end = cells[cell + 1];  // lists are padded to a multiple of four entries
+    const double thr = RT_CERT_EPS * D, delta = sc.prune_delta_coef * (O + sc.prune_radius);
+    // first look in fp32 on the direction scaled to |d|_inf = 1: |error| <= 14 * 2^-24 (three products of factors <= 1, each
+    // operand and operation rounded), so a value above 2^-24 + 2^-20 certifies the entry without the f64 test
+    const float fx = (float)(d.x / D), fy = (float)(d.y / D), fz = (float)(d.z / D);
+    const float thr32 = 0x1p-24f + 0x1p-20f;
+    for (uint32_t e = beg; e < end; e += 4u) {
+        const float4 e0 = entries[e], e1 = entries[e + 1u], e2 = entries[e + 2u], e3 = entries[e + 3u];
+        const float m0 = fabsf(fx * e0.x + fy * e0.y + fz * e0.z), m1 = fabsf(fx * e1.x + fy * e1.y + fz * e1.z);
+        const float m2 = fabsf(fx * e2.x + fy * e2.y + fz * e2.z), m3 = fabsf(fx * e3.x + fy * e3.y + fz * e3.z);
+        if (!(fminf(fminf(m0, m1), fminf(m2, m3)) >= thr32)) {
+            if (!(m0 >= thr32)) cluster_suspects(sc, __builtin_bit_cast(uint32_t, e0.w), o, d, thr, delta, sus);
+            if (!(m1 >= thr32)) cluster_suspects(sc, __builtin_bit_cast(uint32_t, e1.w), o, d, thr, delta, sus);
+            if (!(m2 >= thr32)) cluster_suspects(sc, __builtin_bit_cast(uint32_t, e2.w), o, d, thr, delta, sus);
+            if (!(m3 >= thr32)) cluster_suspects(sc, __builtin_bit_cast(uint32_t, e3.w), o, d, thr, delta, sus);
+        }
     }
-    return ok;
+    return !sus.overflow;
 }
+// everything box_step needs to prune: the local-box filter, the lanes allowed to prune, their suspect leaves
+struct PruneState {
+    StrictFilter sf;
+    lanemask enable;
+    uint32_t s0, s1, s2;
+    bool any_suspect;  // wave-uniform
+};
+RT_DEV lanemask mask_lt_u32(uint32_t v, uint32_t s) { lanemask m; asm("v_cmp_lt_u32_e64 %0, %1, %2" : "=s"(m) : "v"(v), "s"(s)); return m; }
 
 struct RayS { d3 o, d; double time; };  // ray as handed to this traversal level
 // Where a traversal level gets its f64 ray from.  Only the fp32 filter state is live across the hot loop; the exact
@@ -511,7 +567,7 @@ RT_DEV bool box_exact(cptr<rt_node> nodes, uint32_t rec, d3 o, d3 d, double t_mi
 // One record's box test for the wave: returns the mask of lanes that descend and moves the others to skip(record).
 // `strict` (wave-uniform): the record is an inner one, whose local box may prune (StrictFilter).
 template <int B, int MODE, bool COUNT, class RAYSRC, class HIT>
-RT_DEV lanemask box_step(const Window& w, const BoxFilter& bf, const StrictFilter& sf, lanemask sp_enable, bool strict, uint32_t off, uint32_t& wait, uint32_t rec,
+RT_DEV lanemask box_step(const Window& w, const BoxFilter& bf, const PruneState& ps, bool strict, uint32_t off, uint32_t& wait, uint32_t rec,
                          cptr<rt_node> nodes, const RAYSRC& src, HIT& h, double t_min, LaneCount& cnt) {
     const lanemask m_act = mask_reached(off, wait);
 #ifdef RT_TRACE_DIAG
@@ -522,7 +578,13 @@ RT_DEV lanemask box_step(const Window& w, const BoxFilter& bf, const StrictFilte
     if (MODE == BOX_PLAIN) {
         lanemask cp, cf, sp = 0ull;
         box_filter<B>(bf, w, cp, cf);
-        if (strict && sp_enable != 0ull) sp = strict_filter<B + 8>(sf, w) & sp_enable;
+        if (strict && ps.enable != 0ull) {
+            sp = strict_filter<B + 8>(ps.sf, w) & ps.enable;
+            if (ps.any_suspect) {  // a subtree that holds one of the ray's suspect leaves is not pruned
+                const uint32_t span = wword<B + 6>(w) - off;
+                sp &= ~(mask_lt_u32(ps.s0 - off, span) | mask_lt_u32(ps.s1 - off, span) | mask_lt_u32(ps.s2 - off, span));
+            }
+        }
         const lanemask sp_apply = COUNT ? 0ull : sp;  // the counting kernel walks the reference's own visited set
         m_pass = m_act & cp & ~sp_apply;
         if (COUNT || (m_act & ~(cp | cf | sp_apply)) != 0ull) {  // rare: a plane value within the error bound of best / t_min
@@ -590,13 +652,22 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
     const bool prune = LEVEL == 0 && MODE == BOX_PLAIN && sc.prune_on != 0u;
     uint32_t off = first, cur_xf = prune ? sc.prune_xf : RT_NONE;
     lanemask clean = 0ull;
+    PruneState ps;
+    ps.enable = 0ull; ps.s0 = ps.s1 = ps.s2 = 0xFFFFFFFFu; ps.any_suspect = false;
     if (prune) {
         const RayS ray = src.get();
         d3 xo, xd;
         apply_xform(sc, sc.prune_xf, ray, xo, xd);
-        const bool c = active && ray_certified(sc, xd);
+        Suspects sus;
+        const bool c = ray_certified(sc, xo, xd, sus) && active;
         if (COUNT) cnt.uncertified += (active && !c) ? 1u : 0u;
+#ifdef RT_TRACE_DIAG
+        cnt.diag_flags |= (active && !c) ? 2u : 0u;
+        cnt.diag_flags |= (active && sus.leaf[0] != 0xFFFFFFFFu) ? 8u : 0u;
+#endif
         clean = __builtin_amdgcn_ballot_w64(c);
+        ps.s0 = sus.leaf[0]; ps.s1 = sus.leaf[1]; ps.s2 = sus.leaf[2];
+        ps.any_suspect = __builtin_amdgcn_ballot_w64(c && sus.leaf[0] != 0xFFFFFFFFu) != 0ull;
         RT_RECONVERGE();
     }
     const uint64_t base = (uint64_t)sc.stream;
@@ -609,18 +680,20 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
     }
     for (;;) {  // one round per transform the walk has to enter; the END record of the range leaves both loops
         TriFilter tf;
-        StrictFilter sf;
-        lanemask sp_enable = 0ull;
+        ps.enable = 0ull;
         {
             const RayS ray = src.get();
             d3 xo, xd;
             apply_xform(sc, cur_xf, ray, xo, xd);
             tri_filter_init(tf, xo, xd);
             if (prune && cur_xf == sc.prune_xf) {  // inner records carry boxes of THIS space only
-                const bool ok = strict_filter_init(sf, xo, xd, sc);
-                sp_enable = clean & __builtin_amdgcn_ballot_w64(ok);
+                const bool ok = strict_filter_init(ps.sf, xo, xd, sc);
+                ps.enable = clean & __builtin_amdgcn_ballot_w64(ok);
+#ifdef RT_TRACE_DIAG
+                cnt.diag_flags |= (active && !ok) ? 4u : 0u;
+#endif
             } else {
-                sf.inv_xy = sf.invz_cnx = sf.cn_yz = sf.cp_xy = sf.cpz_ = (f2){0.f, 0.f};
+                ps.sf.inv_xy = ps.sf.invz_cnx = ps.sf.cn_yz = ps.sf.cp_xy = ps.sf.cpz_ = (f2){0.f, 0.f};
             }
         }
         uint32_t want = cur_xf;
@@ -646,14 +719,14 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
                 lanemask rejA, rejB;
                 tri_filter(tf, w, rejA, rejB);
                 if ((m_act & ~(rejA & rejB)) != 0ull) {
-                    const lanemask m_pass = box_step<0, MODE, COUNT>(w, bf, sf, 0ull, false, off, wait, rec, nodes, src, h, t_min, cnt);
+                    const lanemask m_pass = box_step<0, MODE, COUNT>(w, bf, ps, false, off, wait, rec, nodes, src, h, t_min, cnt);
                     if ((m_pass & ~(rejA & rejB)) != 0ull) tri2_exact<COUNT, MODE>(sc, node, off, m_pass, rejA, rejB, src, cur_xf, h, t_min, inst_prim, bf, cnt);
                     RT_RECONVERGE();
                 }
                 off += RT_STREAM_REC_TRI2;
                 continue;
             }
-            lanemask m_pass = box_step<0, MODE, COUNT>(w, bf, sf, sp_enable, (rec & RT_STREAM_KIND) == RT_STREAM_INNER, off, wait, rec, nodes, src, h, t_min, cnt);
+            lanemask m_pass = box_step<0, MODE, COUNT>(w, bf, ps, (rec & RT_STREAM_KIND) == RT_STREAM_INNER, off, wait, rec, nodes, src, h, t_min, cnt);
             if (m_pass == 0ull) {
                 off = skip;
             } else if ((rec & RT_STREAM_KIND) == RT_STREAM_INNER) {
@@ -665,7 +738,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
 #ifdef RT_TRACE_DIAG
                     cnt.steps += 1;
 #endif
-                    m_pass = box_step<16, MODE, COUNT>(w, bf, sf, sp_enable, true, off, wait, rec2, nodes, src, h, t_min, cnt);
+                    m_pass = box_step<16, MODE, COUNT>(w, bf, ps, true, off, wait, rec2, nodes, src, h, t_min, cnt);
                     off = m_pass == 0ull ? wword<22>(w) : off + RT_STREAM_REC_INNER;
                 }
             } else if ((rec & RT_STREAM_KIND) == RT_STREAM_SPH2) {  // one or two spheres: exact f64 test (shape.rs:93-121) on inline geometry
@@ -761,7 +834,12 @@ RT_DEV void traverse(const SceneDev& sc, uint32_t first, const RAYSRC& src, HIT&
     // the min/max form of the slab test is exact unless a NaN can appear (zero / non-finite direction or origin): decided per wave
     const bool plain = sc.boxes_finite && __builtin_amdgcn_ballot_w64(odd) == 0ull;
     if (plain) traverse_impl<LEVEL, COUNT, INST, BOX_PLAIN, RAYSRC, HIT>(sc, first, src, h, active, t_min, inst_prim, cnt);
-    else traverse_impl<LEVEL, COUNT, INST, BOX_LITERAL, RAYSRC, HIT>(sc, first, src, h, active, t_min, inst_prim, cnt);
+    else {
+#ifdef RT_TRACE_DIAG
+        if (LEVEL == 0) cnt.diag_flags |= odd ? 1u : 0u;
+#endif
+        traverse_impl<LEVEL, COUNT, INST, BOX_LITERAL, RAYSRC, HIT>(sc, first, src, h, active, t_min, inst_prim, cnt);
+    }
 }
 
 #ifndef RT_TRACE_WAVES
@@ -803,7 +881,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : 
     h.best = t_max; h.prim = RT_NONE; h.inst = RT_NONE;
     LaneCount cnt; cnt.box = cnt.tri = cnt.sph = cnt.bad = 0; cnt.pruned_until = 0; cnt.uncertified = 0;
 #ifdef RT_TRACE_DIAG
-    cnt.steps = cnt.leaf_steps = cnt.cyc_wait = cnt.lane_steps = cnt.exact_box = cnt.exact_tri = 0; cnt.cyc_total = __builtin_readcyclecounter();
+    cnt.steps = cnt.leaf_steps = cnt.cyc_wait = cnt.lane_steps = cnt.exact_box = cnt.exact_tri = 0; cnt.cyc_total = __builtin_readcyclecounter(); cnt.diag_flags = 0;
 #endif
     if (REGS) {
         LaneHitRegs hr; hr.best = t_max; hr.prim = RT_NONE; hr.inst = RT_NONE;
@@ -814,6 +892,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : 
     }
 #ifdef RT_TRACE_DIAG
     cnt.cyc_total = __builtin_readcyclecounter() - cnt.cyc_total;
+    if (cnt.steps > 5000 && (cnt.diag_flags != 0u || lane_id() == 0)) {
+        const RayS r = src.get();
+        printf("[diag-slow] steps %llu lane %u flags %u o %.17g %.17g %.17g d %.17g %.17g %.17g hit %u\n", (unsigned long long)cnt.steps, lane_id(), cnt.diag_flags,
+               r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, (uint32_t)h.prim);
+    }
     const uint64_t lane_steps = wave_sum_u64(cnt.lane_steps);
     if (stats && lane_id() == 0) {
         atomicAdd(&stats[9], (unsigned long long)lane_steps);
@@ -1183,8 +1266,11 @@ struct rt_scene {
     uint8_t* d_stream = nullptr;
     uint32_t* d_node_off = nullptr;
     uint32_t* d_cert_cells = nullptr;
-    uint32_t* d_cert_entries = nullptr;
+    CertEntry* d_cert_entries = nullptr;
     double* d_cert_normals = nullptr;
+    double* d_cert_planes = nullptr;
+    uint32_t* d_cert_plane_off = nullptr;
+    uint32_t* d_cert_plane_leaf = nullptr;
     SceneDev dev{};
     rt_blob_header hdr{};
     std::vector<rt_prim> host_prims;
@@ -1373,7 +1459,12 @@ struct PruneHost {
     uint64_t n_tris = 0, n_prunable_nodes = 0;
     std::vector<float> local_box;          // 6 per node: (lo, hi) per axis in space xf, (-inf, +inf) = never pruned
     std::vector<double> normals;           // 3 per distinct (clustered) unit normal
-    std::vector<uint32_t> cell_off, entries;  // CSR: normals whose "nearly perpendicular" band meets the direction cell
+    std::vector<uint32_t> cell_off;        // CSR over direction cells into entries (lists padded to a multiple of 4 by repeating their last entry)
+    std::vector<CertEntry> entries;        // normals whose "nearly perpendicular" band meets the cell
+    std::vector<uint32_t> plane_off;       // CSR over clusters into planes
+    std::vector<double> planes;            // sorted plane offsets v0 . n^ of the cluster's triangles
+    std::vector<uint32_t> plane_leaf;      // parallel: node index of the triangle's leaf (prepare_scene turns it into the record offset)
+    double delta_coef = 0.0;
 };
 static float f32_up_host(double v) {       // smallest float >= v (NaN / overflow: +inf)
     if (!(v <= 3.4e38)) return std::numeric_limits<float>::infinity();
@@ -1451,13 +1542,14 @@ static void build_prune(const rt_blob_header& h, const rt_node* nodes, const rt_
     std::vector<double> box((size_t)(n1 - n0) * 6);
     double shape_min = 1.0, e_max = 0.0, v_max = 0.0;
     struct Key { int64_t k[3]; bool operator<(const Key& o) const { return std::lexicographical_compare(k, k + 3, o.k, o.k + 3); } };
-    std::vector<std::pair<Key, std::array<double, 3>>> keyed;
+    struct Item { Key first; std::array<double, 3> second, v0; uint32_t node; };
+    std::vector<Item> keyed;
     for (uint32_t i = n0; i < n1; ++i) {
         const rt_node& nd = nodes[i];
         if (!is_tri2(nd) || geom[nd.prim0].xform != R.xf) continue;
         bool good = true;
         double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        std::array<double, 3> nh[2]; int nn = 0;
+        std::array<double, 3> nh[2], vz[2]; int nn = 0;
         double smin = 1.0, emax = 0.0, vmax = 0.0;
         for (uint32_t p : {nd.prim0, nd.prim1}) {
             if (p == RT_NONE) continue;
@@ -1476,6 +1568,7 @@ static void build_prune(const rt_blob_header& h, const rt_node* nodes, const rt_
             int big = 0;
             for (int k = 1; k < 3; ++k) if (std::fabs(n[k]) > std::fabs(n[big])) big = k;
             const double sgn = n[big] < 0.0 ? -1.0 : 1.0;
+            vz[nn] = {v0[0], v0[1], v0[2]};
             nh[nn++] = {sgn * n[0] / len, sgn * n[1] / len, sgn * n[2] / len};
             for (int k = 0; k < 3; ++k) {   // vertices v0, v0 + e1, v0 + e2 (sums rounded outward)
                 const double a = v0[k] + e1[k], c = v0[k] + e2[k];
@@ -1491,7 +1584,7 @@ static void build_prune(const rt_blob_header& h, const rt_node* nodes, const rt_
         for (int t = 0; t < nn; ++t) {
             Key key;
             for (int k = 0; k < 3; ++k) key.k[k] = (int64_t)std::llround(nh[t][k] * 0x1p34);
-            keyed.push_back({key, nh[t]});
+            keyed.push_back({key, nh[t], vz[t], i});
         }
     }
     // inner nodes, bottom-up: prunable iff every leaf below is a good leaf of the space (children: i+1, skip(i+1), ...)
@@ -1521,23 +1614,56 @@ static void build_prune(const rt_blob_header& h, const rt_node* nodes, const rt_
     if (R.n_prunable_nodes == 0 || keyed.empty()) return;
     // distinct normals: members of a cluster differ from its representative by < 2^-33 per component
     std::sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
-    for (size_t i = 0; i < keyed.size(); ++i)
-        if (i == 0 || keyed[i - 1].first < keyed[i].first) { R.normals.push_back(keyed[i].second[0]); R.normals.push_back(keyed[i].second[1]); R.normals.push_back(keyed[i].second[2]); }
+    // ... and, per cluster, the sorted offsets v0 . n^ of its members' planes (second stage of the certificate)
+    R.plane_off.clear(); R.planes.clear(); R.plane_leaf.clear();
+    {
+        std::vector<std::pair<double, uint32_t>> members;
+        auto flush = [&]() {
+            std::sort(members.begin(), members.end());
+            for (auto& m : members) { R.planes.push_back(m.first); R.plane_leaf.push_back(m.second); }
+            members.clear();
+        };
+        for (size_t i = 0; i < keyed.size(); ++i) {
+            if (i == 0 || keyed[i - 1].first < keyed[i].first) {
+                flush();
+                R.normals.push_back(keyed[i].second[0]); R.normals.push_back(keyed[i].second[1]); R.normals.push_back(keyed[i].second[2]);
+                R.plane_off.push_back((uint32_t)R.planes.size());
+            }
+            const double* n = &R.normals[R.normals.size() - 3];
+            members.push_back({keyed[i].v0[0] * n[0] + keyed[i].v0[1] * n[1] + keyed[i].v0[2] * n[2], keyed[i].node});
+        }
+        flush();
+        R.plane_off.push_back((uint32_t)R.planes.size());
+    }
     const size_t M = R.normals.size() / 3;
     if (M > RT_CERT_MAX_NORMALS) { R.normals.clear(); return; }
     const size_t ncell = 3u * (size_t)RT_CERT_K * RT_CERT_K;
     R.cell_off.assign(ncell + 1, 0);
     for (size_t m = 0; m < M; ++m) cert_raster(&R.normals[3 * m], [&](uint32_t c) { ++R.cell_off[c + 1]; });
-    for (size_t c = 0; c < ncell; ++c) R.cell_off[c + 1] += R.cell_off[c];
-    if (R.cell_off[ncell] > 0x7FFFFFFFu) { R.normals.clear(); R.cell_off.clear(); return; }
-    R.entries.assign(R.cell_off[ncell], 0);
+    std::vector<uint32_t> fill(ncell);
     {
-        std::vector<uint32_t> fill(R.cell_off.begin(), R.cell_off.end() - 1);
-        for (size_t m = 0; m < M; ++m) cert_raster(&R.normals[3 * m], [&](uint32_t c) { R.entries[fill[c]++] = (uint32_t)m; });
+        uint64_t total = 0;
+        for (size_t c = 0; c < ncell; ++c) {
+            const uint32_t cnt = R.cell_off[c + 1];
+            R.cell_off[c] = (uint32_t)total; fill[c] = (uint32_t)total;
+            total += (cnt + 3u) & ~3u;
+            if (total > 0x7FFFFFF0ull) { R.normals.clear(); R.cell_off.clear(); return; }
+        }
+        R.cell_off[ncell] = (uint32_t)total;
+        CertEntry none; none.nx = none.ny = none.nz = 0.f; none.cluster = 0xFFFFFFFFu;
+        R.entries.assign((size_t)total, none);
     }
+    for (size_t m = 0; m < M; ++m)
+        cert_raster(&R.normals[3 * m], [&](uint32_t c) {
+            CertEntry& en = R.entries[fill[c]++];
+            en.nx = (float)R.normals[3 * m]; en.ny = (float)R.normals[3 * m + 1]; en.nz = (float)R.normals[3 * m + 2]; en.cluster = (uint32_t)m;
+        });
+    for (size_t c = 0; c < ncell; ++c)  // padding repeats the list's last entry (a repeated test changes nothing)
+        for (uint32_t e = fill[c]; e < R.cell_off[c + 1]; ++e) R.entries[e] = R.entries[fill[c] - 1];
     // tau = tau_coef (|o|_inf + radius) bounds the distance between the ray point the reference accepts and the triangle
     R.shape_min = shape_min;
     R.tau_coef = 0x1p-21 / shape_min;
+    R.delta_coef = 0x1p-20 / shape_min;
     R.radius = v_max + e_max;
     R.box_abs_max = babs;
     R.on = true;
@@ -1785,6 +1911,7 @@ static int prepare_scene(const void* blob, uint64_t nbytes, ScenePrep& P) {
         for (uint32_t i = 0; i < h.n_nodes; ++i) { n_leaf += nodes[i].prim0 != RT_NONE; n_tri_leaf += is_tri2(nodes[i]); }
         P.reg_ray = 2 * n_tri_leaf < n_leaf;
     }
+    for (uint32_t& l : P.prune.plane_leaf) l = rec_off[l];
     P.root_off = h.root_node == h.root_end ? end_off[h.root_end] : rec_off[h.root_node];
     return RT_OK;
 }
@@ -1801,6 +1928,49 @@ int rt_stream_build_host(const void* blob, uint64_t nbytes, void* stream_out, ui
         memcpy(stream_out, P.stream.data(), P.stream.size());
     }
     if (node_off) memcpy(node_off, P.rec_off.data(), P.rec_off.size() * sizeof(uint32_t));
+    return RT_OK;
+}
+
+int rt_prune_info_host(const void* blob, uint64_t nbytes, double* info, uint32_t n_rays, const double* rays, uint8_t* certified) {
+    if (!blob || !info) return fail(RT_ERR_BAD_ARG, "rt_prune_info_host: null argument");
+    ScenePrep P;
+    int rc = prepare_scene(blob, nbytes, P);
+    if (rc != RT_OK) return rc;
+    const PruneHost& R = P.prune;
+    info[0] = R.on ? 1.0 : 0.0; info[1] = (double)R.xf; info[2] = (double)R.n_tris; info[3] = (double)R.n_prunable_nodes;
+    info[4] = (double)(R.normals.size() / 3); info[5] = (double)R.entries.size(); info[6] = R.shape_min; info[7] = R.tau_coef;
+    info[8] = R.delta_coef; info[9] = R.radius; info[10] = R.box_abs_max; info[11] = 0.0;
+    if (n_rays && (!rays || !certified)) return fail(RT_ERR_BAD_ARG, "rt_prune_info_host: null ray arguments");
+    // the device's certificate, restated on the host for rays (o, d) ALREADY in the pruned space (tests compare it with a brute-force scan)
+    for (uint32_t i = 0; i < n_rays; ++i) {
+        const double* o = rays + 6 * (size_t)i; const double* d = o + 3;
+        certified[i] = 0;
+        if (!R.on) continue;
+        const double ax = std::fabs(d[0]), ay = std::fabs(d[1]), az = std::fabs(d[2]);
+        const double D = std::max(std::max(ax, ay), az), O = std::max(std::max(std::fabs(o[0]), std::fabs(o[1])), std::fabs(o[2]));
+        if (!(D >= 0x1p-100 && D <= 0x1p100 && O <= 0x1p100)) continue;
+        const int a = ax >= ay ? (ax >= az ? 0 : 2) : (ay >= az ? 1 : 2);
+        const double u = d[(a + 1) % 3] / d[a], v = d[(a + 2) % 3] / d[a];
+        const double kk = (double)RT_CERT_K * 0.5, top = (double)(RT_CERT_K - 1u);
+        const uint32_t iu = (uint32_t)std::fmin(std::fmax(std::floor((u + 1.0) * kk), 0.0), top), iv = (uint32_t)std::fmin(std::fmax(std::floor((v + 1.0) * kk), 0.0), top);
+        const uint32_t cell = ((uint32_t)a * RT_CERT_K + iv) * RT_CERT_K + iu;
+        const double thr = RT_CERT_EPS * D, delta = R.delta_coef * (O + R.radius);
+        bool ok = true;
+        std::vector<uint32_t> sus;
+        for (uint32_t e = R.cell_off[cell]; e < R.cell_off[cell + 1]; ++e) {
+            const uint32_t c = R.entries[e].cluster;
+            const double* n = &R.normals[3 * (size_t)c];
+            if (std::fabs(d[0] * n[0] + d[1] * n[1] + d[2] * n[2]) >= thr) continue;
+            const double q = o[0] * n[0] + o[1] * n[1] + o[2] * n[2];
+            auto b = R.planes.begin() + R.plane_off[c], e2 = R.planes.begin() + R.plane_off[c + 1];
+            for (auto it = std::lower_bound(b, e2, q - delta); it != e2 && !(*it > q + delta); ++it) {
+                const uint32_t leaf = R.plane_leaf[(size_t)(it - R.planes.begin())];
+                if (std::find(sus.begin(), sus.end(), leaf) == sus.end()) sus.push_back(leaf);
+            }
+        }
+        ok = sus.size() <= RT_SUSPECT_SLOTS;
+        certified[i] = !ok ? 0 : sus.empty() ? 1 : 2;
+    }
     return RT_OK;
 }
 
@@ -1836,10 +2006,16 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     if (pr.on) {
         if (e == hipSuccess) e = hipMalloc((void**)&sc->d_cert_cells, pr.cell_off.size() * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMemcpy(sc->d_cert_cells, pr.cell_off.data(), pr.cell_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMalloc((void**)&sc->d_cert_entries, std::max<size_t>(pr.entries.size(), 1) * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMemcpy(sc->d_cert_entries, pr.entries.data(), pr.entries.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void**)&sc->d_cert_entries, std::max<size_t>(pr.entries.size(), 1) * sizeof(CertEntry));
+        if (e == hipSuccess) e = hipMemcpy(sc->d_cert_entries, pr.entries.data(), pr.entries.size() * sizeof(CertEntry), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMalloc((void**)&sc->d_cert_normals, pr.normals.size() * sizeof(double));
         if (e == hipSuccess) e = hipMemcpy(sc->d_cert_normals, pr.normals.data(), pr.normals.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void**)&sc->d_cert_planes, pr.planes.size() * sizeof(double));
+        if (e == hipSuccess) e = hipMemcpy(sc->d_cert_planes, pr.planes.data(), pr.planes.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void**)&sc->d_cert_plane_off, pr.plane_off.size() * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemcpy(sc->d_cert_plane_off, pr.plane_off.data(), pr.plane_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void**)&sc->d_cert_plane_leaf, pr.plane_leaf.size() * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemcpy(sc->d_cert_plane_leaf, pr.plane_leaf.data(), pr.plane_leaf.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     }
     if (e != hipSuccess) {
         if (sc->dblob) (void)hipFree(sc->dblob);
@@ -1849,6 +2025,9 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
         if (sc->d_cert_cells) (void)hipFree(sc->d_cert_cells);
         if (sc->d_cert_entries) (void)hipFree(sc->d_cert_entries);
         if (sc->d_cert_normals) (void)hipFree(sc->d_cert_normals);
+        if (sc->d_cert_planes) (void)hipFree(sc->d_cert_planes);
+        if (sc->d_cert_plane_off) (void)hipFree(sc->d_cert_plane_off);
+        if (sc->d_cert_plane_leaf) (void)hipFree(sc->d_cert_plane_leaf);
         delete sc;
         return fail(e == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, hipGetErrorString(e));
     }
@@ -1863,6 +2042,7 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     v.stream = sc->d_stream; v.root_off = P.root_off;
     v.node_off = sc->d_node_off; v.box_abs_max = box_abs_max;
     v.cert_cells = sc->d_cert_cells; v.cert_entries = sc->d_cert_entries; v.cert_normals = sc->d_cert_normals;
+    v.cert_planes = sc->d_cert_planes; v.cert_plane_off = sc->d_cert_plane_off; v.cert_plane_leaf = sc->d_cert_plane_leaf; v.prune_delta_coef = pr.delta_coef;
     v.prune_on = pr.on ? 1u : 0u; v.prune_xf = pr.xf;
     v.prune_tau_coef = pr.tau_coef; v.prune_radius = pr.radius; v.prune_box_abs_max = pr.box_abs_max;
     v.n_nodes = h.n_nodes; v.boxes_finite = boxes_finite ? 1u : 0u;
@@ -1905,6 +2085,9 @@ int rt_scene_destroy(rt_scene* sc) {
     if (sc->d_cert_cells) (void)hipFree(sc->d_cert_cells);
     if (sc->d_cert_entries) (void)hipFree(sc->d_cert_entries);
     if (sc->d_cert_normals) (void)hipFree(sc->d_cert_normals);
+    if (sc->d_cert_planes) (void)hipFree(sc->d_cert_planes);
+    if (sc->d_cert_plane_off) (void)hipFree(sc->d_cert_plane_off);
+    if (sc->d_cert_plane_leaf) (void)hipFree(sc->d_cert_plane_leaf);
     delete sc;
     return RT_OK;
 }

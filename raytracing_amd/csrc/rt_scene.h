@@ -31,9 +31,12 @@ struct SceneDev {
     double box_abs_max;        // max |coordinate| over the finite boxes (box filter error bound)
     // strict pruning (rt_device.hip, StrictFilter / ray_certified): one transform space, its direction grid and error constants
     const uint32_t* cert_cells;    // [3 K K + 1] CSR offsets into cert_entries
-    const uint32_t* cert_entries;  // indices into cert_normals
+    const void* cert_entries;      // CertEntry[]: fp32 normal + index into cert_normals, lists padded to multiples of 4
     const double* cert_normals;    // 3 per distinct unit normal of the pruned space
-    double prune_tau_coef, prune_radius, prune_box_abs_max;
+    const double* cert_planes;       // per normal cluster: sorted plane offsets v0 . n^ of its triangles
+    const uint32_t* cert_plane_off;  // [n_normals + 1] CSR offsets into cert_planes
+    const uint32_t* cert_plane_leaf; // parallel to cert_planes: stream offset of the triangle's leaf record
+    double prune_tau_coef, prune_delta_coef, prune_radius, prune_box_abs_max;
     uint32_t prune_on, prune_xf;
     uint32_t root_off;  // first scene-level record in `stream` (the range is closed by an END record)
     rt_camera camera;
