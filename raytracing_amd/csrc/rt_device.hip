@@ -742,16 +742,12 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
                     off = m_pass == 0ull ? wword<22>(w) : off + RT_STREAM_REC_INNER;
                 }
             } else if ((rec & RT_STREAM_KIND) == RT_STREAM_SPH2) {  // one or two spheres: exact f64 test (shape.rs:93-121) on inline geometry
-                if (wword<8>(w) != cur_xf) {
-                    if (COUNT && !(rec & RT_NODE_NO_BOX)) cnt.box -= mask_lane(m_pass) ? 1u : 0u;
-                    want = wword<8>(w);
-                    break;
-                }
+                // the spheres' own transform is applied on the spot: only the triangle filter needs the walk to BE in a space
                 off += RT_STREAM_REC_SPH2;
                 const uint32_t nsph = wword<9>(w);
                 const RayS ray = src.get();
                 d3 xo, xd;
-                apply_xform(sc, cur_xf, ray, xo, xd);
+                apply_xform(sc, wword<8>(w), ray, xo, xd);
                 const bool pass = mask_lane(m_pass);
                 if (COUNT) cnt.sph += pass ? (nsph + ((rec & RT_NODE_DUP_RIGHT) ? 1u : 0u)) : 0u;
                 double t;
@@ -789,20 +785,16 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
                 if (node == RT_STREAM_END_NODE) { want = RT_WALK_DONE; break; }  // END record: every ray still waiting has arrived at the end of the range
                 const uint32_t p0 = wword<8>(w), p1 = wword<9>(w);
                 const bool pass = mask_lane(m_pass);
-                if (wword<10>(w) != cur_xf) {
-                    if (COUNT && !(rec & RT_NODE_NO_BOX)) cnt.box -= pass ? 1u : 0u;
-                    want = wword<10>(w);
-                    break;
-                }
+                const uint32_t x0 = wword<10>(w);  // transform of the first primitive, applied on the spot
                 off += RT_STREAM_REC_LEAF;
                 const GeomS g0 = load_geom(geom, p0);
                 const RayS ray = src.get();
                 d3 xo, xd;
-                apply_xform(sc, cur_xf, ray, xo, xd);
+                apply_xform(sc, x0, ray, xo, xd);
                 bool changed = test_prim<LEVEL, COUNT, INST, HIT>(sc, p0, g0, pass, ray, h, xo, xd, t_min, inst_prim, cnt);
                 if (p1 != RT_NONE) {
                     const GeomS g1 = load_geom(geom, p1);
-                    if (g1.xform == cur_xf) {
+                    if (g1.xform == x0) {
                         changed |= test_prim<LEVEL, COUNT, INST, HIT>(sc, p1, g1, pass, ray, h, xo, xd, t_min, inst_prim, cnt);
                     } else {  // second primitive of a leaf under a different matrix: one-off transform
                         d3 yo, yd;
