@@ -94,7 +94,7 @@ class HostScene:
 
     def prune_info(self, rays=None):
         """Strict-pruning set-up of this scene as rt_scene_upload derives it (host only).  rays: n x 6 (origin, direction) in the
-        pruned space -> also returns which of them the device certifies for pruning."""
+        pruned space -> also returns the device's verdict per ray: 1 certified, 2 certified with protected suspect leaves, 0 walked without pruning."""
         b = self.blob()
         info = np.zeros(12)
         n = 0 if rays is None else len(rays)
@@ -103,7 +103,7 @@ class HostScene:
         _hip_check(_ffi.hip().rt_prune_info_host(b, len(b), info.ctypes.data, n, r.ctypes.data, cert.ctypes.data))
         keys = ("on", "xform", "triangles", "prunable_nodes", "normals", "grid_entries", "shape_min", "tau_coef", "delta_coef", "radius", "box_abs_max")
         d = dict(zip(keys, info))
-        return (d, cert[:n].astype(bool)) if rays is not None else d
+        return (d, cert[:n].copy()) if rays is not None else d
 
     def __del__(self):
         try:

@@ -847,14 +847,16 @@ template <bool COUNT, bool INST, bool REGS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : REGS ? RT_TRACE_WAVES_REGS : RT_TRACE_WAVES))) void k_trace(SceneDev sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_fixed,
                                                const double* __restrict__ rays, uint32_t cap, double t_min, double t_max,
                                                uint32_t* __restrict__ out_prim, uint32_t* __restrict__ out_inst, double* __restrict__ out_t,
-                                               unsigned long long* __restrict__ stats) {
+                                               unsigned long long* __restrict__ stats, uint32_t lanes) {
+    // `lanes` rays per wave (64, or fewer for incoherent queues: the wave walks the UNION of its rays' visited records)
     const uint32_t n = n_ptr ? *n_ptr : n_fixed;
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t wave_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid & ~63u));
+    const uint32_t wave_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)((tid >> 6) * lanes));
     if (tid == 0 && stats) atomicAdd(&stats[0], (unsigned long long)n);  // rays traced
     if (wave_first >= n) return;
-    const bool valid = tid < n;
-    const uint32_t path = valid ? (queue ? queue[tid] : tid) : 0u;
+    const uint32_t slot = wave_first + (tid & 63u);
+    const bool valid = (tid & 63u) < lanes && slot < n;
+    const uint32_t path = valid ? (queue ? queue[slot] : slot) : 0u;
     __shared__ double lds_ray[7 * 256];
     __shared__ double lds_best[256];
     __shared__ uint32_t lds_prim[256], lds_inst[256];
@@ -996,7 +998,22 @@ RT_DEV uint32_t sort_key(const SceneDev& sc, d3 o, d3 d) {
     const float ax = fabsf((float)d.x), ay = fabsf((float)d.y), az = fabsf((float)d.z);
     const float inv = 3.999f / fmaxf(fmaxf(ax, ay), fmaxf(az, 1e-30f));
     const uint32_t dbin = ((uint32_t)(ax * inv) & 3u) | (((uint32_t)(ay * inv) & 3u) << 2) | (((uint32_t)(az * inv) & 3u) << 4);
-    return (oct << 21) | ((spread5(cx) | (spread5(cy) << 1) | (spread5(cz) << 2)) << 6) | dbin;
+#ifndef RT_KEY_VARIANT
+#define RT_KEY_VARIANT 2  /* measured with strict pruning, 16 spp: variant 2 -4 % trace time against 1, variants 3 and 4 no better than 1 */
+#endif
+    const uint32_t morton = spread5(cx) | (spread5(cy) << 1) | (spread5(cz) << 2);
+#if RT_KEY_VARIANT == 1
+    return (oct << 21) | (morton << 6) | dbin;
+#elif RT_KEY_VARIANT == 2   // coarser cells (4 bits per axis), finer directions (3 bits per axis)
+    const float inv8 = 7.999f / fmaxf(fmaxf(ax, ay), fmaxf(az, 1e-30f));
+    const uint32_t d9 = ((uint32_t)(ax * inv8) & 7u) | (((uint32_t)(ay * inv8) & 7u) << 3) | (((uint32_t)(az * inv8) & 7u) << 6);
+    const uint32_t m4 = spread5(cx >> 1) | (spread5(cy >> 1) << 1) | (spread5(cz >> 1) << 2);
+    return (oct << 21) | ((m4 & 0xFFFu) << 9) | d9;
+#elif RT_KEY_VARIANT == 3   // origin-major
+    return (morton << 9) | (oct << 6) | dbin;
+#elif RT_KEY_VARIANT == 4   // cell, then direction, Morton-interleaved pairs: 3 origin bits, then octant, then the rest
+    return ((morton >> 9) << 18) | (oct << 15) | ((morton & 0x1FFu) << 6) | dbin;
+#endif
 }
 #define RT_SORT_BITS 25u  /* 24 key bits + bit 24 = "empty slot" (slots are pre-filled with 0xFFFFFFFF) */
 
@@ -1340,10 +1357,11 @@ struct EventTimer {
 enum { CAT_TRACE = 0, CAT_SHADE = 1, CAT_OTHER = 2, CAT_N = 3 };
 
 static void launch_trace(rt_scene* sc, bool count, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_bound, const double* rays, double t_min,
-                         double t_max, uint32_t* out_prim, uint32_t* out_inst, double* out_t) {
+                         double t_max, uint32_t* out_prim, uint32_t* out_inst, double* out_t, uint32_t lanes = 64u) {
     hipStream_t st = sc->ctx->stream;
     if (n_bound == 0) return;
-#define RT_LAUNCH_TRACE_R(C, I, R) hipLaunchKernelGGL((k_trace<C, I, R>), grid_for(n_bound), dim3(256), 0, st, sc->dev, queue, n_ptr, n_bound, rays, sc->ws.cap, t_min, t_max, out_prim, out_inst, out_t, sc->ws.stats)
+    const dim3 grid((uint32_t)((((uint64_t)n_bound + lanes - 1u) / lanes + 3u) / 4u));  // waves of `lanes` rays, four waves per block
+#define RT_LAUNCH_TRACE_R(C, I, R) hipLaunchKernelGGL((k_trace<C, I, R>), grid, dim3(256), 0, st, sc->dev, queue, n_ptr, n_bound, rays, sc->ws.cap, t_min, t_max, out_prim, out_inst, out_t, sc->ws.stats, lanes)
 #define RT_LAUNCH_TRACE(C, I) do { if (sc->reg_ray) RT_LAUNCH_TRACE_R(C, I, true); else RT_LAUNCH_TRACE_R(C, I, false); } while (0)
     const bool inst = sc->has_instances;  // scenes without BVHNode objects use the kernel variant compiled without the nested walk
 #ifdef RT_TRACE_DIAG
@@ -1393,12 +1411,15 @@ static int run_paths(rt_scene* sc, uint32_t n, bool explicit_lists, uint32_t wid
     tm.end();
     launches += 3;
     int cur = 0;
+    static const uint32_t lanes_b1 = getenv("RT_LANES_B1") ? (uint32_t)atoi(getenv("RT_LANES_B1")) : 64u;
+    static const uint32_t lanes_deep = getenv("RT_LANES_DEEP") ? (uint32_t)atoi(getenv("RT_LANES_DEEP")) : 64u;
     for (int32_t bounce = 0; bounce < max_depth; ++bounce) {
         const int nxt = cur ^ 1;
         HIP_OK(hipMemsetAsync(ws.counts + nxt, 0, sizeof(uint32_t), st));
         HIP_OK(hipMemsetAsync(ws.counts + 2, 0, sizeof(uint32_t), st));
         tm.begin(CAT_TRACE);
-        launch_trace(sc, count_tests, ws.queue[cur], ws.counts + cur, n, ws.pb.rays, 0.001, 100000.0, ws.pb.hit_prim, ws.pb.hit_inst, ws.pb.hit_t);  // integrator.rs:38
+        launch_trace(sc, count_tests, ws.queue[cur], ws.counts + cur, n, ws.pb.rays, 0.001, 100000.0, ws.pb.hit_prim, ws.pb.hit_inst, ws.pb.hit_t,
+                     bounce == 0 ? 64u : bounce == 1 ? lanes_b1 : lanes_deep);  // integrator.rs:38
         tm.end();
         const bool mis_shadow = integrator == RT_INT_MIS && sc->dev.n_lights > 0;
         const bool last_bounce = bounce + 1 >= max_depth;

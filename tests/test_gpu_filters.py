@@ -162,3 +162,62 @@ def test_single_triangle_leaves_and_mixed_leaves(gpu_ctx):
     org = rng.uniform(-6, 6, (n, 3))
     tgt = rng.uniform(-3, 3, (n, 3))
     _check(gpu_ctx, text, _rays_at(tgt, org))
+
+
+def _plane_rays(tris, rng, n):
+    """Rays built to lie in (or within eta of) the plane of some triangle, starting on or just off that plane: the
+    rays for which Moller-Trumbore's det is tiny and the reference may accept anything (mesh.rs:59 rejects only
+    |det| < 2.2e-16) -- the case strict pruning must recognise and never prune on."""
+    k = rng.integers(0, len(tris), n)
+    v0, e1, e2 = tris[k, 0], tris[k, 1] - tris[k, 0], tris[k, 2] - tris[k, 0]
+    nh = np.cross(e1, e2); nh /= np.linalg.norm(nh, axis=1)[:, None]
+    a, b = rng.normal(size=n), rng.normal(size=n)
+    eta = 10.0 ** rng.uniform(-14, -3, n) * rng.choice([-1, 1], n)
+    eta[::4] = 0.0
+    off = 10.0 ** rng.uniform(-12, -1, n) * rng.choice([-1, 1], n)
+    off[::3] = 0.0
+    d = a[:, None] * e1 + b[:, None] * e2
+    d = d / np.abs(d).max(1)[:, None] + eta[:, None] * nh
+    o = v0 + rng.normal(size=(n, 1)) * e1 * 4 + rng.normal(size=(n, 1)) * e2 * 4 + off[:, None] * nh
+    rays = np.zeros((n, 7)); rays[:, :3] = o; rays[:, 3:6] = d
+    return rays
+
+
+@pytest.mark.parametrize("wrap", [None, scale(1.5, 0.75, 1.25), translate(5.0, 5.0, 5.0)])
+def test_strict_pruning_never_loses_a_hit(gpu_ctx, wrap):
+    # 400 triangles (pruning is on from 64), optionally under a transform so that the pruned space is not the world
+    text, tris, rng = _soup(21, 400, 4.0, wrap=wrap)
+    hs = rt.HostScene.from_description(text)
+    assert hs.prune_info()["on"] == 1.0
+    n = 6000
+    m = np.array(wrap if wrap is not None else scale(1, 1, 1), float).reshape(4, 4).T   # space of the triangles -> world
+    org = rng.uniform(-9, 9, (n, 3)); tgt = rng.uniform(-4, 4, (n, 3)) @ m[:3, :3].T + m[:3, 3]
+    o = _check(gpu_ctx, text, _rays_at(tgt, org))                       # ordinary rays
+    assert (o[0] != rt.NONE).sum() > n // 10
+    sky = _rays_at(org * 30.0, org * 3.0)                               # rays that leave the scene: pruned at the top
+    assert (_check(gpu_ctx, text, sky)[0] != rt.NONE).sum() < n // 5
+    # in-plane rays, in the space of the triangles: map them to world space for the wrapped scenes
+    pr = _plane_rays(tris, rng, n)
+    pr[:, :3] = pr[:, :3] @ m[:3, :3].T + m[:3, 3]
+    pr[:, 3:6] = pr[:, 3:6] @ m[:3, :3].T
+    _check(gpu_ctx, text, pr, t_min=0.001, t_max=1e5)
+    _check(gpu_ctx, text, pr, t_min=0.0, t_max=1e300)
+    axis = _rays_at(tgt, org); axis[:, 3:6] = np.eye(3)[rng.integers(0, 3, n)] * rng.choice([-1.0, 1.0], (n, 1))   # zero components: literal path, no pruning
+    _check(gpu_ctx, text, axis)
+
+
+def test_strict_pruning_on_the_pagoda_with_surface_and_plane_rays(gpu_ctx):
+    hs = rt.HostScene.builtin("mesh", bvh_seed=3)
+    text = hs.describe()
+    geo = hs.geoms(); tri = geo[geo["kind"] == 0]["d"]
+    tris = np.stack([tri[:, 0:3], tri[:, 0:3] + tri[:, 3:6], tri[:, 0:3] + tri[:, 6:9]], axis=1)
+    rng = np.random.default_rng(31)
+    n = 8000
+    k = rng.integers(0, len(tris), n)
+    u, v = rng.uniform(0, 1, n), rng.uniform(0, 1, n); fl = u + v > 1; u[fl], v[fl] = 1 - u[fl], 1 - v[fl]
+    p = tris[k, 0] + u[:, None] * (tris[k, 1] - tris[k, 0]) + v[:, None] * (tris[k, 2] - tris[k, 0]) + 5.0   # main.rs:816: the pagoda sits at +5
+    rays = np.zeros((n, 7)); rays[:, :3] = p; rays[:, 3:6] = rng.normal(size=(n, 3))                         # bounce-like rays from the surfaces
+    o = _check(gpu_ctx, text, rays)
+    assert (o[0] != rt.NONE).sum() > n // 3
+    pr = _plane_rays(tris, rng, n); pr[:, :3] += 5.0
+    _check(gpu_ctx, text, pr)

@@ -212,3 +212,102 @@ def test_stream_builder_rejects_what_upload_rejects():
     small = np.zeros(16, np.uint8)
     assert lib.rt_stream_build_host(good, len(good), small.ctypes.data, small.nbytes, rt.C.byref(n), None, None) != 0
     assert b"too small" in lib.rt_last_error()
+
+
+# ---- strict pruning: local boxes and the certificate, checked without a GPU ------------------------
+
+def _soup_scene(seed, n_tri, extent, wrap=None):
+    rng = np.random.default_rng(seed)
+    s = SceneText(bvh_seed=4)
+    m = s.lambertian_rgb(.5, .5, .5)
+    centres = rng.uniform(-extent, extent, (n_tri, 3))
+    verts, faces = [], []
+    for k in range(n_tri):
+        for _ in range(3):
+            verts.append(tuple(centres[k] + rng.normal(size=3) * extent * 0.08))
+        faces.append((3 * k, 3 * k + 1, 3 * k + 2))
+    me = s.mesh(verts, [(0, 0, 1)] * len(verts), [(0, 0)] * len(verts), faces, m)
+    xf = s.xform(wrap) if wrap is not None else None
+    ids = [s.transformed(xf, s.triangle(me, k)) if xf is not None else s.triangle(me, k) for k in range(n_tri)]
+    ids.append(s.sphere((0.0, -extent * 3, 0.0), extent, m))          # a sphere leaf: its ancestors must not be pruned
+    return rt.HostScene.from_description(s.finish(ids, build_bvh=True))
+
+
+def _scene_for(name):
+    if name == "soup":
+        return _soup_scene(5, 300, 4.0)
+    if name == "soup_scaled":
+        return _soup_scene(6, 200, 3.0, wrap=scale(1.5, 0.75, 1.25))
+    return rt.HostScene.builtin(name, bvh_seed=3)
+
+
+@pytest.mark.parametrize("name", ["mesh", "soup", "soup_scaled", "cornell", "random", "simple_triangle"])
+def test_local_boxes_contain_the_triangles_below_them(name):
+    hs = _scene_for(name)
+    h, nodes, geo = hs.header(), hs.nodes(), hs.geoms()
+    info = hs.prune_info()
+    stream, _, node_off = hs.trace_stream()
+    raw = stream.tobytes()
+    inf = float("inf")
+    n_finite = 0
+    for i in range(h.n_nodes):
+        if nodes[i]["prim0"] != rt.NONE:
+            continue
+        lb = np.array(struct.unpack_from("<6f", raw, int(node_off[i]) + 32), np.float64).reshape(3, 2)
+        sub = range(i + 1, int(nodes[i]["skip"]))
+        leaves = [j for j in sub if nodes[j]["prim0"] != rt.NONE]
+        prims = [int(p) for j in leaves for p in (nodes[j]["prim0"], nodes[j]["prim1"]) if p != rt.NONE]
+        all_tri = bool(prims) and all(geo[p]["kind"] == 0 and geo[p]["xform"] == int(info["xform"]) for p in prims)
+        if not np.isfinite(lb).all():
+            assert (lb[:, 0] == -inf).all() and (lb[:, 1] == inf).all()      # never pruned
+            # ... and there is a reason: pruning off, an instance range, or something other than a triangle of the space below
+            assert (not info["on"]) or i >= h.root_end or not all_tri
+            continue
+        n_finite += 1
+        assert info["on"] and i < h.root_end and all_tri
+        d = geo["d"][prims]
+        verts = np.concatenate([d[:, 0:3], d[:, 0:3] + d[:, 3:6], d[:, 0:3] + d[:, 6:9]])
+        assert (verts >= lb[:, 0]).all() and (verts <= lb[:, 1]).all()        # the fp32 box is rounded outward
+        assert (verts.min(0) - lb[:, 0] <= 1e-6 * (1 + np.abs(lb[:, 0]))).all() and (lb[:, 1] - verts.max(0) <= 1e-6 * (1 + np.abs(lb[:, 1]))).all()  # and tight
+    assert n_finite == int(info["prunable_nodes"])
+    if name in ("mesh", "soup", "soup_scaled"):
+        assert info["on"] and n_finite > 0.4 * (nodes["prim0"] == rt.NONE).sum()
+    if name in ("cornell", "random", "simple_triangle"):
+        assert not info["on"]                                                  # instances only / spheres only / 10 triangles
+
+
+def test_certificate_is_conservative_on_the_pagoda():
+    # A ray certified "clean" (code 1) must satisfy, for EVERY triangle of the pruned space, what the proof needs:
+    # |d . n^| >= 2^-25 |d|_inf, or the origin at least delta_B away from the triangle's plane.
+    hs = rt.HostScene.builtin("mesh", bvh_seed=3)
+    info = hs.prune_info()
+    geo = hs.geoms()
+    tri = geo[(geo["kind"] == 0) & (geo["xform"] == int(info["xform"]))]["d"]
+    v0, e1, e2 = tri[:, 0:3], tri[:, 3:6], tri[:, 6:9]
+    n = np.cross(e1, e2); nh = n / np.linalg.norm(n, axis=1)[:, None]
+    rng = np.random.default_rng(11)
+    N = 1500
+    o = rng.uniform(-40, 40, (N, 3)); d = rng.normal(size=(N, 3))
+    # adversarial: direction inside a triangle's plane up to a perturbation eta, origin eps off that plane
+    k = rng.integers(0, len(tri), N)
+    a, b = rng.normal(size=N), rng.normal(size=N)
+    eta = 10.0 ** rng.uniform(-12, -4, N) * rng.choice([-1, 1], N)
+    off = 10.0 ** rng.uniform(-9, 0, N) * rng.choice([-1, 1], N)
+    d_adv = a[:, None] * e1[k] + b[:, None] * e2[k]
+    d_adv = d_adv / np.abs(d_adv).max(1)[:, None] + eta[:, None] * nh[k]
+    o_adv = v0[k] + rng.normal(size=(N, 1)) * e1[k] * 3 + rng.normal(size=(N, 1)) * e2[k] * 3 + off[:, None] * nh[k]
+    O, D = np.concatenate([o, o_adv]), np.concatenate([d, d_adv])
+    _, code_raw = hs.prune_info(np.concatenate([O, D], axis=1))
+    Dinf = np.abs(D).max(1); Oinf = np.abs(O).max(1)
+    V = np.abs(v0).max(); E = max(np.abs(e1).sum(1).max(), np.abs(e2).sum(1).max())
+    delta_b = 4.0 / info["shape_min"] * 2.0 ** -23 * (Oinf + V + E) * (1 + 2.0 ** -10)
+    assert (info["delta_coef"] * (Oinf + info["radius"]) >= delta_b * (1 + 2.0 ** -10)).all()   # the device's delta covers the proof's
+    clean = np.nonzero(code_raw == 1)[0]
+    for i in clean:
+        mu = np.abs(nh @ D[i]); lam = np.abs(((O[i] - v0) * nh).sum(1))
+        bad = (mu < 2.0 ** -25 * Dinf[i]) & (lam < delta_b[i])
+        assert not bad.any(), (i, int(bad.sum()))
+    assert (code_raw[:N] == 1).mean() > 0.99                 # random rays are practically always certified
+    in_plane = (np.abs(eta) < 2.0 ** -26) & (np.abs(off) < 1e-6)
+    assert in_plane.sum() > 20 and (code_raw[N:][in_plane] != 1).all()   # rays lying in a triangle's plane never are
+    assert (code_raw[N:] == 2).sum() > 0                     # and some of them walk with protected leaves
