@@ -551,6 +551,9 @@ enum { BOX_LITERAL = 0, BOX_PLAIN = 1 };
 #ifndef RT_LEAF_FIRST
 #define RT_LEAF_FIRST 1
 #endif
+#ifndef RT_STRICT_FIRST
+#define RT_STRICT_FIRST 1
+#endif
 #define RT_WALK_DONE 0xFFFFFFFEu  /* `want` value that ends the walk (never a transform id: RT_NONE is 0xFFFFFFFF, ids are < n_xforms) */
 template <bool PLAIN>
 RT_DEV bool box_exact(cptr<rt_node> nodes, uint32_t rec, d3 o, d3 d, double t_min, double best) {
@@ -576,8 +579,7 @@ RT_DEV lanemask box_step(const Window& w, const BoxFilter& bf, const PruneState&
     if (COUNT) cnt.box += (mask_lane(m_act) && !(rec & RT_NODE_NO_BOX)) ? 1u : 0u;
     lanemask m_pass;
     if (MODE == BOX_PLAIN) {
-        lanemask cp, cf, sp = 0ull;
-        box_filter<B>(bf, w, cp, cf);
+        lanemask cp = 0ull, cf = 0ull, sp = 0ull;
         if (strict && ps.enable != 0ull) {
             sp = strict_filter<B + 8>(ps.sf, w) & ps.enable;
             if (ps.any_suspect) {  // a subtree that holds one of the ray's suspect leaves is not pruned
@@ -586,6 +588,13 @@ RT_DEV lanemask box_step(const Window& w, const BoxFilter& bf, const PruneState&
             }
         }
         const lanemask sp_apply = COUNT ? 0ull : sp;  // the counting kernel walks the reference's own visited set
+#if RT_STRICT_FIRST
+        if (!COUNT && (m_act & ~sp_apply) == 0ull) {  // every ray that is here is pruned: the reference's own test decides nothing
+            wait = mask_select(wait, wword<B + 6>(w), m_act);
+            return 0ull;
+        }
+#endif
+        box_filter<B>(bf, w, cp, cf);
         m_pass = m_act & cp & ~sp_apply;
         if (COUNT || (m_act & ~(cp | cf | sp_apply)) != 0ull) {  // rare: a plane value within the error bound of best / t_min
             const RayS ray = src.get();
@@ -835,7 +844,7 @@ RT_DEV void traverse(const SceneDev& sc, uint32_t first, const RAYSRC& src, HIT&
 }
 
 #ifndef RT_TRACE_WAVES
-#define RT_TRACE_WAVES 5  /* waves per SIMD the register allocator must leave room for */
+#define RT_TRACE_WAVES 6  /* waves per SIMD the register allocator must leave room for */
 #endif
 #ifndef RT_TRACE_WAVES_REGS
 #define RT_TRACE_WAVES_REGS 3
@@ -2203,15 +2212,14 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
         HIP_OK(hipStreamSynchronize(sc->ctx->stream));
         return RT_OK;
     }
-    // paths in flight: as many as fit in a third of the free HBM (at most 64 GiB) and 64M paths.  Large passes matter:
+    // paths in flight: as many as fit in a third of the free HBM (at most 96 GiB) and 128M paths.  Large passes matter:
     // the deeper bounces carry few rays, and every traversal launch lasts at least as long as its slowest wave
-    // (a wave holding one ray that misses everything sweeps the whole trace stream)
     uint32_t spass = p->samples_per_pass;
     if (spass == 0) {
         size_t free_b = 0, total_b = 0;
         HIP_OK(hipMemGetInfo(&free_b, &total_b));
-        const uint64_t budget = std::min<uint64_t>(64ull << 30, (uint64_t)free_b / 3);
-        uint64_t by_paths = std::max<uint64_t>(1, (64ull << 20) / npix);
+        const uint64_t budget = std::min<uint64_t>(96ull << 30, (uint64_t)free_b / 3);
+        uint64_t by_paths = std::max<uint64_t>(1, (128ull << 20) / npix);
         uint64_t by_mem = std::max<uint64_t>(1, budget / ((uint64_t)npix * ((uint64_t)p->max_depth * REC_FIELDS * 8 + 256)));
         spass = (uint32_t)std::min<uint64_t>(std::min(by_paths, by_mem), 256);
     }
