@@ -107,6 +107,7 @@ RT_DEV GeomS load_geom(cptr<rt_geom> geom, uint32_t p) {
 // next wave-uniform join (ultimately the loop header), and every scalar merged there -- the cursor, the cached
 // transform id -- is classed divergent and moves to VGPRs with exec-masked branches.
 #define RT_RECONVERGE() asm volatile("")
+#define RT_RAY_STRIDE 8u  /* a ray in the path buffers is one 64-byte line: origin, direction, time, pad (two double4) */
 
 // ---- the trace stream ---------------------------------------------------------------------------
 // rt_scene_upload derives from the blob's node / geom tables one pre-order byte stream of FILTER records:
@@ -856,7 +857,7 @@ template <bool COUNT, bool INST, bool REGS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : REGS ? RT_TRACE_WAVES_REGS : RT_TRACE_WAVES))) void k_trace(SceneDev sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_fixed,
                                                const double* __restrict__ rays, uint32_t cap, double t_min, double t_max,
                                                uint32_t* __restrict__ out_prim, uint32_t* __restrict__ out_inst, double* __restrict__ out_t,
-                                               unsigned long long* __restrict__ stats, uint32_t lanes) {
+                                               unsigned long long* __restrict__ stats, uint32_t lanes, uint32_t t_stride) {
     // `lanes` rays per wave (64, or fewer for incoherent queues: the wave walks the UNION of its rays' visited records)
     const uint32_t n = n_ptr ? *n_ptr : n_fixed;
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -871,10 +872,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : 
     __shared__ uint32_t lds_prim[256], lds_inst[256];
     {
         double* slot = &lds_ray[threadIdx.x];
-        slot[0 * 256] = valid ? rays[0 * (size_t)cap + path] : 0.0; slot[1 * 256] = valid ? rays[1 * (size_t)cap + path] : 0.0;
-        slot[2 * 256] = valid ? rays[2 * (size_t)cap + path] : 0.0; slot[3 * 256] = valid ? rays[3 * (size_t)cap + path] : 1.0;
-        slot[4 * 256] = valid ? rays[4 * (size_t)cap + path] : 1.0; slot[5 * 256] = valid ? rays[5 * (size_t)cap + path] : 1.0;
-        slot[6 * 256] = valid ? rays[6 * (size_t)cap + path] : 0.0;
+        const double4* r4 = (const double4*)(rays + (size_t)path * RT_RAY_STRIDE);
+        const double4 a = valid ? r4[0] : make_double4(0.0, 0.0, 0.0, 1.0), b = valid ? r4[1] : make_double4(1.0, 1.0, 0.0, 0.0);
+        slot[0 * 256] = a.x; slot[1 * 256] = a.y; slot[2 * 256] = a.z; slot[3 * 256] = a.w; slot[4 * 256] = b.x; slot[5 * 256] = b.y; slot[6 * 256] = b.z;
     }
     RayFromLds src; src.slot = (lptr<volatile double>)&lds_ray[threadIdx.x];  // each lane reads back only its own slot: no barrier needed
     RayInRegisters src_regs;
@@ -914,7 +914,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : 
         const uint32_t hp = h.prim;
         out_prim[path] = hp;
         if (out_inst) out_inst[path] = (uint32_t)h.inst;
-        out_t[path] = hp != RT_NONE ? (double)h.best : __builtin_nan("");
+        out_t[(size_t)path * t_stride] = hp != RT_NONE ? (double)h.best : __builtin_nan("");
     }
     if (COUNT && stats) {
         uint64_t b = wave_sum_u64(cnt.box), t = wave_sum_u64(cnt.tri), s = wave_sum_u64(cnt.sph), bad = wave_sum_u64(cnt.bad);
@@ -963,9 +963,8 @@ __global__ __launch_bounds__(256) void k_raygen(rt_camera cam, uint32_t width, u
     double time = (cam.time1 - cam.time0) > 0.000001 ? rng.range(cam.time0, cam.time1) : 0.0;
     d3 ro = origin + offset;
     d3 rd = ld3(cam.lower_left_corner) + (ld3(cam.horizontal) * u) + (ld3(cam.vertical) * v) - origin - offset;
-    rays[0 * (size_t)cap + p] = ro.x; rays[1 * (size_t)cap + p] = ro.y; rays[2 * (size_t)cap + p] = ro.z;
-    rays[3 * (size_t)cap + p] = rd.x; rays[4 * (size_t)cap + p] = rd.y; rays[5 * (size_t)cap + p] = rd.z;
-    rays[6 * (size_t)cap + p] = time;
+    double4* r4 = (double4*)(rays + (size_t)p * RT_RAY_STRIDE);
+    r4[0] = make_double4(ro.x, ro.y, ro.z, rd.x); r4[1] = make_double4(rd.y, rd.z, time, 0.0);
     path_pixel[p] = pixel; path_sample[p] = sample;
     if (nb) nb[p] = 0u;
 }
@@ -973,10 +972,10 @@ __global__ __launch_bounds__(256) void k_raygen(rt_camera cam, uint32_t width, u
 // ------------------------------------------------------------------------------------------------
 // k_shade: one ray_colour level (integrator.rs) for every live path
 // ------------------------------------------------------------------------------------------------
-// Bounce record, SoA [depth][REC_FIELDS][cap].  With emitted == 0 for every scattering material:
+// Bounce record, [depth][cap][REC_STRIDE] (a path's record is one 96-byte block: paths are shaded in sorted, not path, order).  With emitted == 0 for every scattering material:
 //   not visible / no light sample:  L = (brdf*cos*L_next)/pdf              (integrator.rs:62-66,164-168,224,291,361)
 //   light visible (MIS):            L = (brdf*cos*L_next*w)/pdf + C_l      (integrator.rs:138-154), w gated by L_next >= .001
-enum { REC_BRDF_X = 0, REC_BRDF_Y, REC_BRDF_Z, REC_COS, REC_PDF, REC_W, REC_CL_X, REC_CL_Y, REC_CL_Z, REC_T_LIGHT, REC_T_SHADOW, REC_FIELDS };
+enum { REC_BRDF_X = 0, REC_BRDF_Y, REC_BRDF_Z, REC_COS, REC_PDF, REC_W, REC_CL_X, REC_CL_Y, REC_CL_Z, REC_T_LIGHT, REC_T_SHADOW, REC_FIELDS, REC_STRIDE = 12 };
 
 struct PathBuffers {
     double* rays;        // [7][cap]
@@ -986,7 +985,7 @@ struct PathBuffers {
     uint32_t* path_pixel; uint32_t* path_sample;
     uint32_t* nb;        // records written per path
     double* terminal;    // [3][cap] radiance returned by the last ray_colour level
-    double* records;     // [depth][REC_FIELDS][cap]
+    double* records;     // [depth][cap][REC_STRIDE]
     double* radiance;    // [3][cap]
     uint32_t cap;
 };
@@ -1066,9 +1065,9 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, PathBuffers pb, cons
     if (valid) {
         path = queue[gid];
         Ray ray;
-        ray.o = mk(pb.rays[0 * (size_t)cap + path], pb.rays[1 * (size_t)cap + path], pb.rays[2 * (size_t)cap + path]);
-        ray.d = mk(pb.rays[3 * (size_t)cap + path], pb.rays[4 * (size_t)cap + path], pb.rays[5 * (size_t)cap + path]);
-        ray.time = pb.rays[6 * (size_t)cap + path];
+        const double4* r4 = (const double4*)(pb.rays + (size_t)path * RT_RAY_STRIDE);
+        const double4 ra = r4[0], rb = r4[1];
+        ray.o = mk(ra.x, ra.y, ra.z); ray.d = mk(ra.w, rb.x, rb.y); ray.time = rb.z;
         const uint32_t prim = pb.hit_prim[path];
         d3 terminal = mk(0.0, 0.0, 0.0);
         bool done = false;
@@ -1127,9 +1126,8 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, PathBuffers pb, cons
                             double light_weight = power_heuristic(light_pdf_value, pdf_value(material_pdf, light_dir));
                             double light_cos_theta = fmax(dot(hr.normal, light_dir), 0.0);
                             c_l = material_brdf(sc, mat, hr, light_dir) * light_cos_theta * light_emit * light_weight / light_pdf_value;
-                            pb.shadow_rays[0 * (size_t)cap + path] = hr.point.x; pb.shadow_rays[1 * (size_t)cap + path] = hr.point.y; pb.shadow_rays[2 * (size_t)cap + path] = hr.point.z;
-                            pb.shadow_rays[3 * (size_t)cap + path] = light_dir.x; pb.shadow_rays[4 * (size_t)cap + path] = light_dir.y; pb.shadow_rays[5 * (size_t)cap + path] = light_dir.z;
-                            pb.shadow_rays[6 * (size_t)cap + path] = ray.time;
+                            double4* s4 = (double4*)(pb.shadow_rays + (size_t)path * RT_RAY_STRIDE);
+                            s4[0] = make_double4(hr.point.x, hr.point.y, hr.point.z, light_dir.x); s4[1] = make_double4(light_dir.y, light_dir.z, ray.time, 0.0);
                             want_shadow = true;
                             shadow_key = sort_key(sc, hr.point, light_dir);
                         }
@@ -1151,25 +1149,25 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, PathBuffers pb, cons
                     brdf = material_brdf(sc, mat, hr, out_dir);
                 }
                 if (!done) {
-                    double* rec = pb.records + (size_t)bounce * REC_FIELDS * cap + path;
-                    rec[REC_BRDF_X * (size_t)cap] = brdf.x; rec[REC_BRDF_Y * (size_t)cap] = brdf.y; rec[REC_BRDF_Z * (size_t)cap] = brdf.z;
-                    rec[REC_COS * (size_t)cap] = cos_theta; rec[REC_PDF * (size_t)cap] = pdf; rec[REC_W * (size_t)cap] = w;
-                    rec[REC_CL_X * (size_t)cap] = c_l.x; rec[REC_CL_Y * (size_t)cap] = c_l.y; rec[REC_CL_Z * (size_t)cap] = c_l.z;
-                    rec[REC_T_LIGHT * (size_t)cap] = t_light;
+                    double* rec = pb.records + ((size_t)bounce * cap + path) * REC_STRIDE;
+                    rec[REC_BRDF_X] = brdf.x; rec[REC_BRDF_Y] = brdf.y; rec[REC_BRDF_Z] = brdf.z;
+                    rec[REC_COS] = cos_theta; rec[REC_PDF] = pdf; rec[REC_W] = w;
+                    rec[REC_CL_X] = c_l.x; rec[REC_CL_Y] = c_l.y; rec[REC_CL_Z] = c_l.z;
+                    rec[REC_T_LIGHT] = t_light;
                     pb.nb[path] = bounce + 1u;
                     if ((int32_t)(bounce + 1u) >= max_depth) {  // next level has depth <= 0: returns 0 without tracing (integrator.rs:33-35)
                         terminal = mk(0.0, 0.0, 0.0);
                         done = true;
                     } else {
-                        pb.rays[0 * (size_t)cap + path] = hr.point.x; pb.rays[1 * (size_t)cap + path] = hr.point.y; pb.rays[2 * (size_t)cap + path] = hr.point.z;
-                        pb.rays[3 * (size_t)cap + path] = out_dir.x; pb.rays[4 * (size_t)cap + path] = out_dir.y; pb.rays[5 * (size_t)cap + path] = out_dir.z;
+                        double4* n4 = (double4*)(pb.rays + (size_t)path * RT_RAY_STRIDE);
+                        n4[0] = make_double4(hr.point.x, hr.point.y, hr.point.z, out_dir.x); n4[1] = make_double4(out_dir.y, out_dir.z, ray.time, 0.0);
                         want_next = true;
                         next_key = sort_key(sc, hr.point, out_dir);
                     }
                 }
             }
         }
-        if (done) { pb.terminal[0 * (size_t)cap + path] = terminal.x; pb.terminal[1 * (size_t)cap + path] = terminal.y; pb.terminal[2 * (size_t)cap + path] = terminal.z; }
+        if (done) { pb.terminal[(size_t)path * 4u + 0] = terminal.x; pb.terminal[(size_t)path * 4u + 1] = terminal.y; pb.terminal[(size_t)path * 4u + 2] = terminal.z; }
     }
     push_queue_keyed(want_next, path, next_key, next_queue, next_keys, next_count);
     push_queue_keyed(want_shadow, path, shadow_key, shadow_queue, shadow_keys, shadow_count);
@@ -1182,22 +1180,22 @@ __global__ __launch_bounds__(256) void k_unwind(PathBuffers pb, uint32_t n) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const size_t cap = pb.cap;
-    d3 L = mk(pb.terminal[0 * cap + p], pb.terminal[1 * cap + p], pb.terminal[2 * cap + p]);
+    d3 L = mk(pb.terminal[(size_t)p * 4u + 0], pb.terminal[(size_t)p * 4u + 1], pb.terminal[(size_t)p * 4u + 2]);
     for (int k = (int)pb.nb[p] - 1; k >= 0; --k) {
-        const double* rec = pb.records + (size_t)k * REC_FIELDS * cap + p;
-        d3 brdf = mk(rec[REC_BRDF_X * cap], rec[REC_BRDF_Y * cap], rec[REC_BRDF_Z * cap]);
-        double cos_theta = rec[REC_COS * cap], pdf = rec[REC_PDF * cap], t_light = rec[REC_T_LIGHT * cap];
+        const double* rec = pb.records + ((size_t)k * cap + p) * REC_STRIDE;
+        d3 brdf = mk(rec[REC_BRDF_X], rec[REC_BRDF_Y], rec[REC_BRDF_Z]);
+        double cos_theta = rec[REC_COS], pdf = rec[REC_PDF], t_light = rec[REC_T_LIGHT];
         bool visible = false;
         if (t_light == t_light) {  // a light sample was taken: visible iff the shadow ray hit and |t_scene - t_light| <= 1e-4 (integrator.rs:82-86)
-            double t_shadow = rec[REC_T_SHADOW * cap];
+            double t_shadow = rec[REC_T_SHADOW];
             visible = (t_shadow == t_shadow) && !(fabs(t_shadow - t_light) > 0.0001);
         }
         d3 e = mk(0.0, 0.0, 0.0);  // emitted of a scattering material
         if (visible) {
             bool has_light = L.x >= 0.001 && L.y >= 0.001 && L.z >= 0.001;  // integrator.rs:119-121
-            double w = has_light ? rec[REC_W * cap] : 0.0;
+            double w = has_light ? rec[REC_W] : 0.0;
             d3 material_contribution = brdf * cos_theta * L * w / pdf;
-            d3 c_l = mk(rec[REC_CL_X * cap], rec[REC_CL_Y * cap], rec[REC_CL_Z * cap]);
+            d3 c_l = mk(rec[REC_CL_X], rec[REC_CL_Y], rec[REC_CL_Z]);
             L = e + material_contribution + c_l;
         } else {
             L = e + (brdf * cos_theta * L) / pdf;
@@ -1237,13 +1235,13 @@ __global__ void k_aos_to_soa(const double* __restrict__ aos, uint32_t n, double*
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
 #pragma unroll
-    for (int c = 0; c < 7; ++c) soa[(size_t)c * cap + i] = aos[(size_t)i * 7 + c];
+    for (int c = 0; c < 7; ++c) soa[(size_t)i * RT_RAY_STRIDE + c] = aos[(size_t)i * 7 + c];
 }
 __global__ void k_soa_to_aos(const double* __restrict__ soa, uint32_t n, uint32_t cap, double* __restrict__ aos) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
 #pragma unroll
-    for (int c = 0; c < 7; ++c) aos[(size_t)i * 7 + c] = soa[(size_t)c * cap + i];
+    for (int c = 0; c < 7; ++c) aos[(size_t)i * 7 + c] = soa[(size_t)i * RT_RAY_STRIDE + c];
 }
 __global__ void k_iota(uint32_t* q, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1316,11 +1314,11 @@ static int ws_ensure(rt_scene* sc, uint32_t cap, int32_t depth) {
     cap = (cap + 255u) & ~255u;
     int rc;
 #define WS(ptr, count) if ((rc = ws_alloc(ws, ptr, (size_t)(count))) != RT_OK) { ws_free(ws); return rc; }
-    WS(ws.pb.rays, 7 * (size_t)cap) WS(ws.pb.shadow_rays, 7 * (size_t)cap)
+    WS(ws.pb.rays, RT_RAY_STRIDE * (size_t)cap) WS(ws.pb.shadow_rays, RT_RAY_STRIDE * (size_t)cap)
     WS(ws.pb.hit_prim, cap) WS(ws.pb.hit_inst, cap) WS(ws.pb.hit_t, cap) WS(ws.pb.shadow_prim, cap)
     WS(ws.pb.path_pixel, cap) WS(ws.pb.path_sample, cap) WS(ws.pb.nb, cap)
-    WS(ws.pb.terminal, 3 * (size_t)cap) WS(ws.pb.radiance, 3 * (size_t)cap)
-    WS(ws.pb.records, (size_t)std::max(depth, 1) * REC_FIELDS * cap)
+    WS(ws.pb.terminal, 4 * (size_t)cap) WS(ws.pb.radiance, 3 * (size_t)cap)
+    WS(ws.pb.records, (size_t)std::max(depth, 1) * REC_STRIDE * cap)
     WS(ws.queue[0], cap) WS(ws.queue[1], cap) WS(ws.shadow_queue, cap) WS(ws.counts, 4) WS(ws.stats, 16)
     WS(ws.in_pixel, cap) WS(ws.in_sample, cap)
     WS(ws.raw_queue, cap) WS(ws.raw_keys, cap) WS(ws.raw_squeue, cap) WS(ws.raw_skeys, cap) WS(ws.sorted_keys, cap)
@@ -1366,11 +1364,11 @@ struct EventTimer {
 enum { CAT_TRACE = 0, CAT_SHADE = 1, CAT_OTHER = 2, CAT_N = 3 };
 
 static void launch_trace(rt_scene* sc, bool count, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_bound, const double* rays, double t_min,
-                         double t_max, uint32_t* out_prim, uint32_t* out_inst, double* out_t, uint32_t lanes = 64u) {
+                         double t_max, uint32_t* out_prim, uint32_t* out_inst, double* out_t, uint32_t lanes = 64u, uint32_t t_stride = 1u) {
     hipStream_t st = sc->ctx->stream;
     if (n_bound == 0) return;
     const dim3 grid((uint32_t)((((uint64_t)n_bound + lanes - 1u) / lanes + 3u) / 4u));  // waves of `lanes` rays, four waves per block
-#define RT_LAUNCH_TRACE_R(C, I, R) hipLaunchKernelGGL((k_trace<C, I, R>), grid, dim3(256), 0, st, sc->dev, queue, n_ptr, n_bound, rays, sc->ws.cap, t_min, t_max, out_prim, out_inst, out_t, sc->ws.stats, lanes)
+#define RT_LAUNCH_TRACE_R(C, I, R) hipLaunchKernelGGL((k_trace<C, I, R>), grid, dim3(256), 0, st, sc->dev, queue, n_ptr, n_bound, rays, sc->ws.cap, t_min, t_max, out_prim, out_inst, out_t, sc->ws.stats, lanes, t_stride)
 #define RT_LAUNCH_TRACE(C, I) do { if (sc->reg_ray) RT_LAUNCH_TRACE_R(C, I, true); else RT_LAUNCH_TRACE_R(C, I, false); } while (0)
     const bool inst = sc->has_instances;  // scenes without BVHNode objects use the kernel variant compiled without the nested walk
 #ifdef RT_TRACE_DIAG
@@ -1452,7 +1450,7 @@ static int run_paths(rt_scene* sc, uint32_t n, bool explicit_lists, uint32_t wid
         if (mis_shadow) {
             tm.begin(CAT_TRACE);
             launch_trace(sc, count_tests, ws.shadow_queue, ws.counts + 2, n, ws.pb.shadow_rays, 0.001, 10000.0, ws.pb.shadow_prim, nullptr,
-                         ws.pb.records + ((size_t)bounce * REC_FIELDS + REC_T_SHADOW) * ws.cap);  // integrator.rs:82
+                         ws.pb.records + (size_t)bounce * ws.cap * REC_STRIDE + REC_T_SHADOW, 64u, (uint32_t)REC_STRIDE);  // integrator.rs:82
             tm.end();
             launches += 1;
         }
@@ -2136,9 +2134,9 @@ int rt_trace_closest(rt_scene* sc, uint32_t n, const double* rays, double t_min,
     if (rc != RT_OK) return rc;
     Workspace& ws = sc->ws;
     hipStream_t st = sc->ctx->stream;
-    std::vector<double> soa(7 * (size_t)ws.cap, 0.0);
+    std::vector<double> soa(RT_RAY_STRIDE * (size_t)n, 0.0);  // internal layout: one 64-byte line per ray
     for (uint32_t i = 0; i < n; ++i)
-        for (int c = 0; c < 7; ++c) soa[(size_t)c * ws.cap + i] = rays[(size_t)i * 7 + c];
+        for (int c = 0; c < 7; ++c) soa[(size_t)i * RT_RAY_STRIDE + c] = rays[(size_t)i * 7 + c];
     HIP_OK(hipMemcpyAsync(ws.pb.rays, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_OK(hipMemsetAsync(ws.stats, 0, 16 * sizeof(unsigned long long), st));
     launch_trace(sc, counters != nullptr, nullptr, nullptr, n, ws.pb.rays, t_min, t_max, ws.pb.hit_prim, ws.pb.hit_inst, ws.pb.hit_t);
@@ -2220,7 +2218,7 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
         HIP_OK(hipMemGetInfo(&free_b, &total_b));
         const uint64_t budget = std::min<uint64_t>(96ull << 30, (uint64_t)free_b / 3);
         uint64_t by_paths = std::max<uint64_t>(1, (128ull << 20) / npix);
-        uint64_t by_mem = std::max<uint64_t>(1, budget / ((uint64_t)npix * ((uint64_t)p->max_depth * REC_FIELDS * 8 + 256)));
+        uint64_t by_mem = std::max<uint64_t>(1, budget / ((uint64_t)npix * ((uint64_t)p->max_depth * REC_STRIDE * 8 + 320)));
         spass = (uint32_t)std::min<uint64_t>(std::min(by_paths, by_mem), 256);
     }
     spass = std::min(spass, spp);

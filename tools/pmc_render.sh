@@ -10,7 +10,7 @@ acc=collections.defaultdict(float); n=collections.defaultdict(int)
 for d in ("a","b"):
     for f in glob.glob("gpurun_out/pmc_${tag}_%s/*/*counter_collection.csv"%d):
         for r in csv.DictReader(open(f)):
-            if "k_trace" in r["Kernel_Name"]:
+            if "${KFILTER:-k_trace}" in r["Kernel_Name"]:
                 acc[r["Counter_Name"]]+=float(r["Counter_Value"]); n[r["Counter_Name"]]+=1
 w=acc.get("SQ_WAVES",1)
 print("k_trace dispatches:", n.get("SQ_WAVES"))

@@ -11,7 +11,7 @@ acc=collections.defaultdict(float); n=collections.defaultdict(int)
 for d in ("f","w"):
     for f in glob.glob("gpurun_out/pmc_${tag}_%s/*/*counter_collection.csv"%d):
         for r in csv.DictReader(open(f)):
-            if "k_trace" in r["Kernel_Name"]:
+            if "${KFILTER:-k_trace}" in r["Kernel_Name"]:
                 acc[r["Counter_Name"]]+=float(r["Counter_Value"]); n[r["Counter_Name"]]+=1
 L=max(n.get("FETCH_SIZE",1),1)
 out={"workload":"pagoda_1080p_brdf","spp_per_step":$spp,"k_trace_launches":L,
