@@ -212,9 +212,10 @@ int rt_prune_info_host(const void* blob, uint64_t nbytes, double* info, uint32_t
 /* Scene::hit for n rays (scene.rs:31-38).  rays: n x 7 doubles (ox,oy,oz,dx,dy,dz,time), host.
  * Outputs (host): prim_id = object id of the closest primitive or RT_NONE; inst_id = enclosing
  * Transformed object id or RT_NONE (may be NULL); t = ray parameter (0 on miss).
- * counters (host, may be NULL): 4 x u64 = box, triangle, sphere tests summed over the batch (reference order),
- * then the number of fp32 filter decisions the exact f64 test contradicted (0 by construction: the counting
- * kernel evaluates both for every decision). */
+ * counters (host, may be NULL): 8 x u64 = box, triangle, sphere tests summed over the batch (reference order: the
+ * counting kernel walks the reference's full visited set), then the number of decisions of the production kernel's
+ * shortcuts the exact walk contradicted (fp32 filter verdicts, accepts inside a subtree strict pruning would skip:
+ * 0 by construction), then the number of rays that would be walked without a pruning certificate; 3 reserved. */
 int rt_trace_closest(rt_scene* scene, uint32_t n, const double* rays, double t_min, double t_max,
                      uint32_t* prim_id, uint32_t* inst_id, double* t, uint64_t* counters);
 /* Same, everything already resident: rays_dev n x 7 doubles, outputs device arrays; asynchronous on
