@@ -1272,6 +1272,7 @@ struct Workspace {
     uint32_t* raw_queue = nullptr; uint32_t* raw_keys = nullptr; uint32_t* raw_squeue = nullptr; uint32_t* raw_skeys = nullptr; uint32_t* sorted_keys = nullptr;  // ray sorting
     void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     uint32_t cap = 0; int32_t depth = 0;
+    uint32_t* h_counts = nullptr;  // pinned host copy of counts (the live ray count of the next bounce sizes its sort and launches)
     std::vector<void*> allocs;
 };
 
@@ -1298,6 +1299,7 @@ struct rt_scene {
 
 static void ws_free(Workspace& ws) {
     for (void* p : ws.allocs) (void)hipFree(p);
+    if (ws.h_counts) (void)hipHostFree(ws.h_counts);
     ws = Workspace();
 }
 template <class T> static int ws_alloc(Workspace& ws, T*& out, size_t count) {
@@ -1331,6 +1333,7 @@ static int ws_ensure(rt_scene* sc, uint32_t cap, int32_t depth) {
         ws.sort_tmp = tmp; ws.sort_tmp_bytes = bytes;
     }
 #undef WS
+    if (hipHostMalloc((void**)&ws.h_counts, 4 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { ws_free(ws); return fail(RT_ERR_OOM, "pinned host allocation failed"); }
     ws.pb.cap = cap; ws.cap = cap; ws.depth = depth;
     return RT_OK;
 }
@@ -1418,43 +1421,45 @@ static int run_paths(rt_scene* sc, uint32_t n, bool explicit_lists, uint32_t wid
     tm.end();
     launches += 3;
     int cur = 0;
-    static const uint32_t lanes_b1 = getenv("RT_LANES_B1") ? (uint32_t)atoi(getenv("RT_LANES_B1")) : 64u;
-    static const uint32_t lanes_deep = getenv("RT_LANES_DEEP") ? (uint32_t)atoi(getenv("RT_LANES_DEEP")) : 64u;
-    for (int32_t bounce = 0; bounce < max_depth; ++bounce) {
+    uint32_t live = n;  // rays in queue[cur]: read back after every shade (one 8-byte copy and a stream sync per bounce), so
+                        // that sorts and launches of the thin deeper bounces are sized to the survivors, not to the pass
+    for (int32_t bounce = 0; bounce < max_depth && live > 0; ++bounce) {
         const int nxt = cur ^ 1;
         HIP_OK(hipMemsetAsync(ws.counts + nxt, 0, sizeof(uint32_t), st));
         HIP_OK(hipMemsetAsync(ws.counts + 2, 0, sizeof(uint32_t), st));
         tm.begin(CAT_TRACE);
-        launch_trace(sc, count_tests, ws.queue[cur], ws.counts + cur, n, ws.pb.rays, 0.001, 100000.0, ws.pb.hit_prim, ws.pb.hit_inst, ws.pb.hit_t,
-                     bounce == 0 ? 64u : bounce == 1 ? lanes_b1 : lanes_deep);  // integrator.rs:38
+        launch_trace(sc, count_tests, ws.queue[cur], ws.counts + cur, live, ws.pb.rays, 0.001, 100000.0, ws.pb.hit_prim, ws.pb.hit_inst, ws.pb.hit_t);  // integrator.rs:38
         tm.end();
         const bool mis_shadow = integrator == RT_INT_MIS && sc->dev.n_lights > 0;
         const bool last_bounce = bounce + 1 >= max_depth;
         tm.begin(CAT_SHADE);
-        if (sort_rays) {
-            // shade appends survivors and their coherence keys to the raw queues; the sorted order lands in queue[nxt] / shadow_queue
-            HIP_OK(hipMemsetAsync(ws.raw_keys, 0xFF, (size_t)n * sizeof(uint32_t), st));
-            if (mis_shadow) HIP_OK(hipMemsetAsync(ws.raw_skeys, 0xFF, (size_t)n * sizeof(uint32_t), st));
-            hipLaunchKernelGGL(k_shade, grid_for(n), dim3(256), 0, st, sc->dev, ws.pb, ws.queue[cur], ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
+        // shade appends survivors (and, when sorting, their coherence keys) compactly to the raw queues
+        if (sort_rays)
+            hipLaunchKernelGGL(k_shade, grid_for(live), dim3(256), 0, st, sc->dev, ws.pb, ws.queue[cur], ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
                                seed, ws.raw_queue, ws.raw_keys, ws.counts + nxt, ws.raw_squeue, ws.raw_skeys, ws.counts + 2);
-            int rc = RT_OK;
-            if (mis_shadow) rc = sort_queue(sc, n, ws.raw_skeys, ws.raw_squeue, ws.shadow_queue);
-            if (rc == RT_OK && !last_bounce) rc = sort_queue(sc, n, ws.raw_keys, ws.raw_queue, ws.queue[nxt]);
-            if (rc != RT_OK) return rc;
-        } else {
-            hipLaunchKernelGGL(k_shade, grid_for(n), dim3(256), 0, st, sc->dev, ws.pb, ws.queue[cur], ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
+        else
+            hipLaunchKernelGGL(k_shade, grid_for(live), dim3(256), 0, st, sc->dev, ws.pb, ws.queue[cur], ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
                                seed, ws.queue[nxt], (uint32_t*)nullptr, ws.counts + nxt, ws.shadow_queue, (uint32_t*)nullptr, ws.counts + 2);
+        HIP_OK(hipMemcpyAsync(ws.h_counts, ws.counts, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        const uint32_t next_live = std::min(ws.h_counts[nxt], n), shadow_live = std::min(ws.h_counts[2], n);
+        if (sort_rays) {  // the sorted order lands in queue[nxt] / shadow_queue
+            int rc = RT_OK;
+            if (mis_shadow && shadow_live) rc = sort_queue(sc, shadow_live, ws.raw_skeys, ws.raw_squeue, ws.shadow_queue);
+            if (rc == RT_OK && !last_bounce && next_live) rc = sort_queue(sc, next_live, ws.raw_keys, ws.raw_queue, ws.queue[nxt]);
+            if (rc != RT_OK) return rc;
         }
         tm.end();
         launches += 2;
-        if (mis_shadow) {
+        if (mis_shadow && shadow_live) {
             tm.begin(CAT_TRACE);
-            launch_trace(sc, count_tests, ws.shadow_queue, ws.counts + 2, n, ws.pb.shadow_rays, 0.001, 10000.0, ws.pb.shadow_prim, nullptr,
+            launch_trace(sc, count_tests, ws.shadow_queue, ws.counts + 2, shadow_live, ws.pb.shadow_rays, 0.001, 10000.0, ws.pb.shadow_prim, nullptr,
                          ws.pb.records + (size_t)bounce * ws.cap * REC_STRIDE + REC_T_SHADOW, 64u, (uint32_t)REC_STRIDE);  // integrator.rs:82
             tm.end();
             launches += 1;
         }
         cur = nxt;
+        live = next_live;
     }
     tm.begin(CAT_OTHER);
     hipLaunchKernelGGL(k_unwind, grid_for(n), dim3(256), 0, st, ws.pb, n);
