@@ -108,6 +108,8 @@ RT_DEV GeomS load_geom(cptr<rt_geom> geom, uint32_t p) {
 // transform id -- is classed divergent and moves to VGPRs with exec-masked branches.
 #define RT_RECONVERGE() asm volatile("")
 #define RT_RAY_STRIDE 8u  /* a ray in the path buffers is one 64-byte line: origin, direction, time, pad (two double4) */
+struct __attribute__((aligned(16))) PathHit { double t; uint32_t prim, inst; };            // closest hit of a path's current ray
+struct __attribute__((aligned(16))) PathInfo { uint32_t pixel, sample, nb, pad; };         // nb: bounce records written
 
 // ---- the trace stream ---------------------------------------------------------------------------
 // rt_scene_upload derives from the blob's node / geom tables one pre-order byte stream of FILTER records:
@@ -857,7 +859,7 @@ template <bool COUNT, bool INST, bool REGS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : REGS ? RT_TRACE_WAVES_REGS : RT_TRACE_WAVES))) void k_trace(SceneDev sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_fixed,
                                                const double* __restrict__ rays, uint32_t cap, double t_min, double t_max,
                                                uint32_t* __restrict__ out_prim, uint32_t* __restrict__ out_inst, double* __restrict__ out_t,
-                                               unsigned long long* __restrict__ stats, uint32_t lanes, uint32_t t_stride) {
+                                               unsigned long long* __restrict__ stats, uint32_t lanes, uint32_t t_stride, PathHit* __restrict__ out_hit) {
     // `lanes` rays per wave (64, or fewer for incoherent queues: the wave walks the UNION of its rays' visited records)
     const uint32_t n = n_ptr ? *n_ptr : n_fixed;
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -912,9 +914,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : 
 #endif
     if (valid) {
         const uint32_t hp = h.prim;
-        out_prim[path] = hp;
-        if (out_inst) out_inst[path] = (uint32_t)h.inst;
-        out_t[(size_t)path * t_stride] = hp != RT_NONE ? (double)h.best : __builtin_nan("");
+        const double ht = hp != RT_NONE ? (double)h.best : __builtin_nan("");
+        if (out_hit) {  // the render loop: one 16-byte block per path
+            PathHit ph; ph.t = ht; ph.prim = hp; ph.inst = (uint32_t)h.inst;
+            out_hit[path] = ph;
+        } else {
+            if (out_prim) out_prim[path] = hp;
+            if (out_inst) out_inst[path] = (uint32_t)h.inst;
+            out_t[(size_t)path * t_stride] = ht;
+        }
     }
     if (COUNT && stats) {
         uint64_t b = wave_sum_u64(cnt.box), t = wave_sum_u64(cnt.tri), s = wave_sum_u64(cnt.sph), bad = wave_sum_u64(cnt.bad);
@@ -947,8 +955,7 @@ RT_DEV uint32_t tiled_pixel(uint32_t q, uint32_t width, uint32_t height) {
 }
 __global__ __launch_bounds__(256) void k_raygen(rt_camera cam, uint32_t width, uint32_t height, uint32_t n, uint32_t sample0, uint32_t npix,
                                                 const uint32_t* __restrict__ in_pixel, const uint32_t* __restrict__ in_sample, uint64_t seed,
-                                                double* __restrict__ rays, uint32_t cap, uint32_t* __restrict__ path_pixel, uint32_t* __restrict__ path_sample,
-                                                uint32_t* __restrict__ nb, uint32_t tiled) {
+                                                double* __restrict__ rays, uint32_t cap, PathInfo* __restrict__ info, uint32_t tiled) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const uint32_t pixel = in_pixel ? in_pixel[p] : (tiled ? tiled_pixel(p % npix, width, height) : p % npix);
@@ -965,8 +972,7 @@ __global__ __launch_bounds__(256) void k_raygen(rt_camera cam, uint32_t width, u
     d3 rd = ld3(cam.lower_left_corner) + (ld3(cam.horizontal) * u) + (ld3(cam.vertical) * v) - origin - offset;
     double4* r4 = (double4*)(rays + (size_t)p * RT_RAY_STRIDE);
     r4[0] = make_double4(ro.x, ro.y, ro.z, rd.x); r4[1] = make_double4(rd.y, rd.z, time, 0.0);
-    path_pixel[p] = pixel; path_sample[p] = sample;
-    if (nb) nb[p] = 0u;
+    if (info) { PathInfo pi; pi.pixel = pixel; pi.sample = sample; pi.nb = 0u; pi.pad = 0u; info[p] = pi; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -980,10 +986,9 @@ enum { REC_BRDF_X = 0, REC_BRDF_Y, REC_BRDF_Z, REC_COS, REC_PDF, REC_W, REC_CL_X
 struct PathBuffers {
     double* rays;        // [7][cap]
     double* shadow_rays; // [7][cap]
-    uint32_t* hit_prim; uint32_t* hit_inst; double* hit_t;
-    uint32_t* shadow_prim;
-    uint32_t* path_pixel; uint32_t* path_sample;
-    uint32_t* nb;        // records written per path
+    uint32_t* hit_prim; uint32_t* hit_inst; double* hit_t;  // rt_trace_closest only
+    PathHit* hit;        // [cap] closest hit of the current ray
+    PathInfo* info;      // [cap] pixel, sample, records written
     double* terminal;    // [3][cap] radiance returned by the last ray_colour level
     double* records;     // [depth][cap][REC_STRIDE]
     double* radiance;    // [3][cap]
@@ -1068,12 +1073,13 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, PathBuffers pb, cons
         const double4* r4 = (const double4*)(pb.rays + (size_t)path * RT_RAY_STRIDE);
         const double4 ra = r4[0], rb = r4[1];
         ray.o = mk(ra.x, ra.y, ra.z); ray.d = mk(ra.w, rb.x, rb.y); ray.time = rb.z;
-        const uint32_t prim = pb.hit_prim[path];
+        const PathHit ph = pb.hit[path];
+        const uint32_t prim = ph.prim;
         d3 terminal = mk(0.0, 0.0, 0.0);
         bool done = false;
         HitRecord hr;
         if (prim == RT_NONE) { terminal = background_colour(sc.background, ray); done = true; }  // integrator.rs:39-41
-        else if (!full_hit(sc, prim, pb.hit_inst[path], ray, 0.001, pb.hit_t[path], hr)) { terminal = mk(__builtin_nan(""), __builtin_nan(""), __builtin_nan("")); done = true; }  // cannot happen: poison loudly
+        else if (!full_hit(sc, prim, ph.inst, ray, 0.001, ph.t, hr)) { terminal = mk(__builtin_nan(""), __builtin_nan(""), __builtin_nan("")); done = true; }  // cannot happen: poison loudly
         if (!done) {
             const rt_material mat = sc.materials[hr.material];
             Pdf material_pdf;
@@ -1081,7 +1087,8 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, PathBuffers pb, cons
                 terminal = material_emitted(sc, hr.material, hr.u, hr.v, hr.point);
                 done = true;
             } else {
-                Rng rng(seed, pb.path_pixel[path], pb.path_sample[path], bounce + 1u);
+                const PathInfo pi = pb.info[path];
+                Rng rng(seed, pi.pixel, pi.sample, bounce + 1u);
                 const double nan = __builtin_nan("");
                 d3 brdf, out_dir, c_l = mk(0.0, 0.0, 0.0);
                 double cos_theta, pdf = 1.0, w = 0.0, t_light = nan;
@@ -1154,7 +1161,7 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, PathBuffers pb, cons
                     rec[REC_COS] = cos_theta; rec[REC_PDF] = pdf; rec[REC_W] = w;
                     rec[REC_CL_X] = c_l.x; rec[REC_CL_Y] = c_l.y; rec[REC_CL_Z] = c_l.z;
                     rec[REC_T_LIGHT] = t_light;
-                    pb.nb[path] = bounce + 1u;
+                    pb.info[path].nb = bounce + 1u;
                     if ((int32_t)(bounce + 1u) >= max_depth) {  // next level has depth <= 0: returns 0 without tracing (integrator.rs:33-35)
                         terminal = mk(0.0, 0.0, 0.0);
                         done = true;
@@ -1181,7 +1188,7 @@ __global__ __launch_bounds__(256) void k_unwind(PathBuffers pb, uint32_t n) {
     if (p >= n) return;
     const size_t cap = pb.cap;
     d3 L = mk(pb.terminal[(size_t)p * 4u + 0], pb.terminal[(size_t)p * 4u + 1], pb.terminal[(size_t)p * 4u + 2]);
-    for (int k = (int)pb.nb[p] - 1; k >= 0; --k) {
+    for (int k = (int)pb.info[p].nb - 1; k >= 0; --k) {
         const double* rec = pb.records + ((size_t)k * cap + p) * REC_STRIDE;
         d3 brdf = mk(rec[REC_BRDF_X], rec[REC_BRDF_Y], rec[REC_BRDF_Z]);
         double cos_theta = rec[REC_COS], pdf = rec[REC_PDF], t_light = rec[REC_T_LIGHT];
@@ -1205,11 +1212,11 @@ __global__ __launch_bounds__(256) void k_unwind(PathBuffers pb, uint32_t n) {
 }
 
 // per pixel: fixed-order f64 sum over this pass's samples, then one fp32 add into the accumulator
-__global__ __launch_bounds__(256) void k_accumulate(const double* __restrict__ radiance, const uint32_t* __restrict__ path_pixel, uint32_t cap, uint32_t npix, uint32_t samples,
+__global__ __launch_bounds__(256) void k_accumulate(const double* __restrict__ radiance, const PathInfo* __restrict__ info, uint32_t cap, uint32_t npix, uint32_t samples,
                                                     float* __restrict__ accum) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;  // slot of the sample layer (k_raygen: every layer uses the same slot -> pixel map)
     if (q >= npix) return;
-    const uint32_t px = path_pixel[q];
+    const uint32_t px = info[q].pixel;
     double r = 0.0, g = 0.0, b = 0.0;
     for (uint32_t s = 0; s < samples; ++s) {
         size_t p = (size_t)s * npix + q;
@@ -1317,8 +1324,8 @@ static int ws_ensure(rt_scene* sc, uint32_t cap, int32_t depth) {
     int rc;
 #define WS(ptr, count) if ((rc = ws_alloc(ws, ptr, (size_t)(count))) != RT_OK) { ws_free(ws); return rc; }
     WS(ws.pb.rays, RT_RAY_STRIDE * (size_t)cap) WS(ws.pb.shadow_rays, RT_RAY_STRIDE * (size_t)cap)
-    WS(ws.pb.hit_prim, cap) WS(ws.pb.hit_inst, cap) WS(ws.pb.hit_t, cap) WS(ws.pb.shadow_prim, cap)
-    WS(ws.pb.path_pixel, cap) WS(ws.pb.path_sample, cap) WS(ws.pb.nb, cap)
+    WS(ws.pb.hit_prim, cap) WS(ws.pb.hit_inst, cap) WS(ws.pb.hit_t, cap)
+    WS(ws.pb.hit, cap) WS(ws.pb.info, cap)
     WS(ws.pb.terminal, 4 * (size_t)cap) WS(ws.pb.radiance, 3 * (size_t)cap)
     WS(ws.pb.records, (size_t)std::max(depth, 1) * REC_STRIDE * cap)
     WS(ws.queue[0], cap) WS(ws.queue[1], cap) WS(ws.shadow_queue, cap) WS(ws.counts, 4) WS(ws.stats, 16)
@@ -1367,11 +1374,11 @@ struct EventTimer {
 enum { CAT_TRACE = 0, CAT_SHADE = 1, CAT_OTHER = 2, CAT_N = 3 };
 
 static void launch_trace(rt_scene* sc, bool count, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_bound, const double* rays, double t_min,
-                         double t_max, uint32_t* out_prim, uint32_t* out_inst, double* out_t, uint32_t lanes = 64u, uint32_t t_stride = 1u) {
+                         double t_max, uint32_t* out_prim, uint32_t* out_inst, double* out_t, uint32_t lanes = 64u, uint32_t t_stride = 1u, PathHit* out_hit = nullptr) {
     hipStream_t st = sc->ctx->stream;
     if (n_bound == 0) return;
     const dim3 grid((uint32_t)((((uint64_t)n_bound + lanes - 1u) / lanes + 3u) / 4u));  // waves of `lanes` rays, four waves per block
-#define RT_LAUNCH_TRACE_R(C, I, R) hipLaunchKernelGGL((k_trace<C, I, R>), grid, dim3(256), 0, st, sc->dev, queue, n_ptr, n_bound, rays, sc->ws.cap, t_min, t_max, out_prim, out_inst, out_t, sc->ws.stats, lanes, t_stride)
+#define RT_LAUNCH_TRACE_R(C, I, R) hipLaunchKernelGGL((k_trace<C, I, R>), grid, dim3(256), 0, st, sc->dev, queue, n_ptr, n_bound, rays, sc->ws.cap, t_min, t_max, out_prim, out_inst, out_t, sc->ws.stats, lanes, t_stride, out_hit)
 #define RT_LAUNCH_TRACE(C, I) do { if (sc->reg_ray) RT_LAUNCH_TRACE_R(C, I, true); else RT_LAUNCH_TRACE_R(C, I, false); } while (0)
     const bool inst = sc->has_instances;  // scenes without BVHNode objects use the kernel variant compiled without the nested walk
 #ifdef RT_TRACE_DIAG
@@ -1414,8 +1421,8 @@ static int run_paths(rt_scene* sc, uint32_t n, bool explicit_lists, uint32_t wid
     const uint32_t npix = width * height;
     tm.begin(CAT_OTHER);
     hipLaunchKernelGGL(k_raygen, grid_for(n), dim3(256), 0, st, sc->dev.camera, width, height, n, sample0, npix,
-                       explicit_lists ? ws.in_pixel : nullptr, explicit_lists ? ws.in_sample : nullptr, seed, ws.pb.rays, ws.cap, ws.pb.path_pixel,
-                       ws.pb.path_sample, ws.pb.nb, explicit_lists ? 0u : 1u);
+                       explicit_lists ? ws.in_pixel : nullptr, explicit_lists ? ws.in_sample : nullptr, seed, ws.pb.rays, ws.cap, ws.pb.info,
+                       explicit_lists ? 0u : 1u);
     hipLaunchKernelGGL(k_iota, grid_for(n), dim3(256), 0, st, ws.queue[0], n);
     hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, ws.counts + 0, n);
     tm.end();
@@ -1428,7 +1435,7 @@ static int run_paths(rt_scene* sc, uint32_t n, bool explicit_lists, uint32_t wid
         HIP_OK(hipMemsetAsync(ws.counts + nxt, 0, sizeof(uint32_t), st));
         HIP_OK(hipMemsetAsync(ws.counts + 2, 0, sizeof(uint32_t), st));
         tm.begin(CAT_TRACE);
-        launch_trace(sc, count_tests, ws.queue[cur], ws.counts + cur, live, ws.pb.rays, 0.001, 100000.0, ws.pb.hit_prim, ws.pb.hit_inst, ws.pb.hit_t);  // integrator.rs:38
+        launch_trace(sc, count_tests, ws.queue[cur], ws.counts + cur, live, ws.pb.rays, 0.001, 100000.0, nullptr, nullptr, nullptr, 64u, 1u, ws.pb.hit);  // integrator.rs:38
         tm.end();
         const bool mis_shadow = integrator == RT_INT_MIS && sc->dev.n_lights > 0;
         const bool last_bounce = bounce + 1 >= max_depth;
@@ -1453,7 +1460,7 @@ static int run_paths(rt_scene* sc, uint32_t n, bool explicit_lists, uint32_t wid
         launches += 2;
         if (mis_shadow && shadow_live) {
             tm.begin(CAT_TRACE);
-            launch_trace(sc, count_tests, ws.shadow_queue, ws.counts + 2, shadow_live, ws.pb.shadow_rays, 0.001, 10000.0, ws.pb.shadow_prim, nullptr,
+            launch_trace(sc, count_tests, ws.shadow_queue, ws.counts + 2, shadow_live, ws.pb.shadow_rays, 0.001, 10000.0, nullptr, nullptr,
                          ws.pb.records + (size_t)bounce * ws.cap * REC_STRIDE + REC_T_SHADOW, 64u, (uint32_t)REC_STRIDE);  // integrator.rs:82
             tm.end();
             launches += 1;
@@ -2174,7 +2181,7 @@ int rt_primary_rays(rt_scene* sc, uint32_t width, uint32_t height, uint32_t samp
     Workspace& ws = sc->ws;
     hipStream_t st = sc->ctx->stream;
     hipLaunchKernelGGL(k_raygen, grid_for(n), dim3(256), 0, st, sc->dev.camera, width, height, n, sample, n, (const uint32_t*)nullptr, (const uint32_t*)nullptr, seed,
-                       ws.pb.rays, ws.cap, ws.pb.path_pixel, ws.pb.path_sample, (uint32_t*)nullptr, 0u);
+                       ws.pb.rays, ws.cap, (PathInfo*)nullptr, 0u);
     double* aos = nullptr;
     HIP_OK(hipMalloc((void**)&aos, (size_t)n * 7 * sizeof(double)));
     hipLaunchKernelGGL(k_soa_to_aos, grid_for(n), dim3(256), 0, st, ws.pb.rays, n, ws.cap, aos);
@@ -2246,7 +2253,7 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
         rc = run_paths(sc, n, false, p->width, p->height, s0, p->max_depth, p->integrator, p->seed, count_tests, sort_rays, tm, launches);
         if (rc != RT_OK) return rc;
         tm.begin(CAT_OTHER);
-        hipLaunchKernelGGL(k_accumulate, grid_for(npix), dim3(256), 0, st, ws.pb.radiance, ws.pb.path_pixel, ws.cap, npix, ns, accum_dev);
+        hipLaunchKernelGGL(k_accumulate, grid_for(npix), dim3(256), 0, st, ws.pb.radiance, ws.pb.info, ws.cap, npix, ns, accum_dev);
         tm.end();
         launches += 1;
     }
