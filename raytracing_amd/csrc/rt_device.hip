@@ -467,7 +467,7 @@ struct RayS { d3 o, d; double time; };  // ray as handed to this traversal level
 // the top level parks it in LDS (14 KB per block; volatile reads stay inside the rare blocks), an instance
 // level keeps the transformed ray it was handed in registers.
 struct RayFromLds {
-    lptr<volatile double> slot;  // &lds[threadIdx.x]; component c at slot[c * 256]
+    lptr<volatile double> slot;  // &lds[threadIdx.x]; component c at slot[c * 256]; 7..9 = 1/d (bounding_box.rs:29), computed once per ray
     RT_DEV RayS get() const {
         RayS r;
         r.o = mk(slot[0 * 256], slot[1 * 256], slot[2 * 256]);
@@ -475,10 +475,13 @@ struct RayFromLds {
         r.time = slot[6 * 256];
         return r;
     }
+    RT_DEV d3 inv() const { return mk(slot[7 * 256], slot[8 * 256], slot[9 * 256]); }
 };
 struct RayInRegisters {
     RayS r;
+    d3 rinv;
     RT_DEV RayS get() const { return r; }
+    RT_DEV d3 inv() const { return rinv; }
 };
 
 template <int LEVEL, bool COUNT, bool INST, class RAYSRC, class HIT>
@@ -526,7 +529,7 @@ RT_DEV bool test_prim(const SceneDev& sc, uint32_t p, const GeomS& g, bool pass,
         double t;
         if (pass && rect_hit(g.d[0], g.d[1], g.d[2], g.d[3], g.d[4], xo, xd, t_min, h.best, t)) { h.best = t; h.prim = p; h.inst = inst_prim; changed = true; }
     } else if constexpr (LEVEL == 0 && INST) {  // RT_PRIM_INSTANCE: BVHNode object (optionally under a Transformed), main.rs:161-188
-        RayInRegisters sub; sub.r.o = xo; sub.r.d = xd; sub.r.time = ray.time;
+        RayInRegisters sub; sub.r.o = xo; sub.r.d = xd; sub.r.time = ray.time; sub.rinv = mk(1.0 / xd.x, 1.0 / xd.y, 1.0 / xd.z);
         const double before = h.best;
         cptr<uint32_t> node_off = as_const(sc.node_off);
         traverse<1, COUNT, INST, RayInRegisters, HIT>(sc, node_off[(uint32_t)g.d[0]], sub, h, pass, t_min, p, cnt);
@@ -559,10 +562,9 @@ enum { BOX_LITERAL = 0, BOX_PLAIN = 1 };
 #endif
 #define RT_WALK_DONE 0xFFFFFFFEu  /* `want` value that ends the walk (never a transform id: RT_NONE is 0xFFFFFFFF, ids are < n_xforms) */
 template <bool PLAIN>
-RT_DEV bool box_exact(cptr<rt_node> nodes, uint32_t rec, d3 o, d3 d, double t_min, double best) {
+RT_DEV bool box_exact(cptr<rt_node> nodes, uint32_t rec, d3 o, d3 inv, double t_min, double best) {
     if (rec & RT_NODE_NO_BOX) return true;  // hittable.rs:41-53: list items are tested without a box (also the END record, which has no node)
     const RT_CONST rt_node& nd = nodes[rec >> 8];
-    const d3 inv = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);  // bounding_box.rs:29 (re-derived: not worth three live register pairs)
     if (PLAIN)
         return box_axis_fast(nd.bmin[0], nd.bmax[0], o.x, inv.x, t_min, best) & box_axis_fast(nd.bmin[1], nd.bmax[1], o.y, inv.y, t_min, best) &
                box_axis_fast(nd.bmin[2], nd.bmax[2], o.z, inv.z, t_min, best);
@@ -602,7 +604,7 @@ RT_DEV lanemask box_step(const Window& w, const BoxFilter& bf, const PruneState&
         if (COUNT || (m_act & ~(cp | cf | sp_apply)) != 0ull) {  // rare: a plane value within the error bound of best / t_min
             const RayS ray = src.get();
             const bool act = mask_lane(m_act);
-            const bool ex = act & box_exact<true>(nodes, rec, ray.o, ray.d, t_min, h.best);
+            const bool ex = act & box_exact<true>(nodes, rec, ray.o, src.inv(), t_min, h.best);
             if (COUNT) {
                 cnt.bad += (act & ((mask_lane(cp) & !ex) | (mask_lane(cf) & ex))) ? 1u : 0u;
                 if (ex && mask_lane(sp) && off >= cnt.pruned_until) cnt.pruned_until = wword<B + 6>(w);  // pruning would skip up to here
@@ -614,7 +616,7 @@ RT_DEV lanemask box_step(const Window& w, const BoxFilter& bf, const PruneState&
         }
     } else {
         const RayS ray = src.get();
-        m_pass = __builtin_amdgcn_ballot_w64(mask_lane(m_act) & box_exact<false>(nodes, rec, ray.o, ray.d, t_min, h.best));
+        m_pass = __builtin_amdgcn_ballot_w64(mask_lane(m_act) & box_exact<false>(nodes, rec, ray.o, src.inv(), t_min, h.best));
     }
     wait = mask_select(wait, wword<B + 6>(w), m_act & ~m_pass);
     return m_pass;
@@ -688,7 +690,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
     BoxFilter bf;
     if (MODE == BOX_PLAIN) {
         const RayS ray = src.get();
-        box_filter_init(bf, ray.o, mk(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z), t_min, h.best, sc.box_abs_max);
+        box_filter_init(bf, ray.o, src.inv(), t_min, h.best, sc.box_abs_max);
     }
     for (;;) {  // one round per transform the walk has to enter; the END record of the range leaves both loops
         TriFilter tf;
@@ -832,7 +834,7 @@ RT_DEV void traverse(const SceneDev& sc, uint32_t first, const RAYSRC& src, HIT&
     bool odd;
     {
         const RayS ray = src.get();
-        const d3 inv = mk(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);  // bounding_box.rs:29
+        const d3 inv = src.inv();  // bounding_box.rs:29
         odd = active && !(ray_is_plain(ray.o, inv) && t_min <= h.best);
     }
     // the min/max form of the slab test is exact unless a NaN can appear (zero / non-finite direction or origin): decided per wave
@@ -869,7 +871,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : 
     const uint32_t slot = wave_first + (tid & 63u);
     const bool valid = (tid & 63u) < lanes && slot < n;
     const uint32_t path = valid ? (queue ? queue[slot] : slot) : 0u;
-    __shared__ double lds_ray[7 * 256];
+    __shared__ double lds_ray[10 * 256];
     __shared__ double lds_best[256];
     __shared__ uint32_t lds_prim[256], lds_inst[256];
     {
@@ -877,10 +879,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : 
         const double4* r4 = (const double4*)(rays + (size_t)path * RT_RAY_STRIDE);
         const double4 a = valid ? r4[0] : make_double4(0.0, 0.0, 0.0, 1.0), b = valid ? r4[1] : make_double4(1.0, 1.0, 0.0, 0.0);
         slot[0 * 256] = a.x; slot[1 * 256] = a.y; slot[2 * 256] = a.z; slot[3 * 256] = a.w; slot[4 * 256] = b.x; slot[5 * 256] = b.y; slot[6 * 256] = b.z;
+        slot[7 * 256] = 1.0 / a.w; slot[8 * 256] = 1.0 / b.x; slot[9 * 256] = 1.0 / b.y;
     }
     RayFromLds src; src.slot = (lptr<volatile double>)&lds_ray[threadIdx.x];  // each lane reads back only its own slot: no barrier needed
     RayInRegisters src_regs;
-    if (REGS) src_regs.r = src.get();
+    if (REGS) { src_regs.r = src.get(); src_regs.rinv = src.inv(); }
     LaneHit h;
     h.best.p = (lptr<volatile double>)&lds_best[threadIdx.x]; h.prim.p = (lptr<volatile uint32_t>)&lds_prim[threadIdx.x]; h.inst.p = (lptr<volatile uint32_t>)&lds_inst[threadIdx.x];
     h.best = t_max; h.prim = RT_NONE; h.inst = RT_NONE;
