@@ -323,8 +323,8 @@ RT_DEV void tri_filter(const TriFilter& f, const Window& w, lanemask& rejA, lane
 // most of the tree.  The result, however, is decided by the triangles the reference ACCEPTS, and the walk may skip any
 // subtree that holds none of those (the remaining visits happen in the same order with the same running best, so every
 // accept, every tie and the final hit are unchanged -- DESIGN.md section 5, "Strict pruning", has the argument in full).
-// A subtree is skipped when the ray's LINE certainly misses the box of the subtree's triangles (taken in the
-// triangles' own space, so no transform enters the argument) inflated by tau:
+// A subtree is skipped when the ray's LINE certainly misses the box of the subtree's primitives (triangles, spheres,
+// moving spheres; taken in the primitives' own space, so no transform enters the argument) inflated by tau:
 //   * accepted triangle T, ray (o, d) in T's space  =>  the real point o + T^ d (T^ the exact solution the computed
 //     u, v, t approximate) lies within tau = tau_coef (|o|_inf + radius) of T, PROVIDED the ray is not nearly
 //     parallel to T's plane: |d.n^_T| >= 2^-25 |d|_inf.  (Nearly parallel rays make det tiny against its rounding
@@ -425,6 +425,7 @@ RT_DEV bool ray_certified(const SceneDev& sc, d3 o, d3 d, Suspects& sus) {
     const double ax = fabs(d.x), ay = fabs(d.y), az = fabs(d.z);
     const double D = fmax(fmax(ax, ay), az), O = fmax(fmax(fabs(o.x), fabs(o.y)), fabs(o.z));
     if (!(D >= 0x1p-100 && D <= 0x1p100 && O <= 0x1p100)) return false;  // also NaN
+    if (sc.cert_n_normals == 0u) return true;  // a pruned space of spheres only: nothing can be nearly coplanar
     const int a = ax >= ay ? (ax >= az ? 0 : 2) : (ay >= az ? 1 : 2);
     const double da = a == 0 ? d.x : a == 1 ? d.y : d.z, db = a == 0 ? d.y : a == 1 ? d.z : d.x, dc = a == 0 ? d.z : a == 1 ? d.x : d.y;
     const double u = db / da, v = dc / da;
@@ -673,7 +674,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
         d3 xo, xd;
         apply_xform(sc, sc.prune_xf, ray, xo, xd);
         Suspects sus;
-        const bool c = ray_certified(sc, xo, xd, sus) && active;
+        const bool c = ray_certified(sc, xo, xd, sus) && active && ray.time >= sc.prune_time0 && ray.time <= sc.prune_time1;
         if (COUNT) cnt.uncertified += (active && !c) ? 1u : 0u;
 #ifdef RT_TRACE_DIAG
         cnt.diag_flags |= (active && !c) ? 2u : 0u;
@@ -1500,6 +1501,8 @@ struct PruneHost {
     std::vector<double> planes;            // sorted plane offsets v0 . n^ of the cluster's triangles
     std::vector<uint32_t> plane_leaf;      // parallel: node index of the triangle's leaf (prepare_scene turns it into the record offset)
     double delta_coef = 0.0;
+    bool has_moving = false;               // a covered moving sphere: pruning only for rays inside the camera's shutter
+    double time0 = 0.0, time1 = 0.0;
 };
 static float f32_up_host(double v) {       // smallest float >= v (NaN / overflow: +inf)
     if (!(v <= 3.4e38)) return std::numeric_limits<float>::infinity();
@@ -1543,8 +1546,8 @@ static void cert_raster(const double* n, EMIT&& emit) {
         }
     }
 }
-template <class IS_TRI2>
-static void build_prune(const rt_blob_header& h, const rt_node* nodes, const rt_geom* geom, IS_TRI2&& is_tri2, PruneHost& R) {
+template <class IS_TRI2, class IS_SPH2>
+static void build_prune(const rt_blob_header& h, const rt_node* nodes, const rt_geom* geom, IS_TRI2&& is_tri2, IS_SPH2&& is_sph2, PruneHost& R) {
     const float inf = std::numeric_limits<float>::infinity();
     R.local_box.assign((size_t)h.n_nodes * 6, 0.f);
     for (size_t i = 0; i < (size_t)h.n_nodes; ++i)
@@ -1558,20 +1561,21 @@ static void build_prune(const rt_blob_header& h, const rt_node* nodes, const rt_
             open.push_back(nodes[i].skip);
         }
     }
-    // the space with the most filter-leaf triangles
+    // the space with the most triangles / spheres / moving spheres
+    auto coverable = [](uint32_t kind) { return kind == RT_PRIM_TRIANGLE || kind == RT_PRIM_SPHERE || kind == RT_PRIM_MOVING_SPHERE; };
     std::vector<std::pair<uint32_t, uint64_t>> per_xf;
-    for (uint32_t i = h.root_node; i < h.root_end; ++i) {
-        if (!is_tri2(nodes[i])) continue;
-        const uint32_t xf = geom[nodes[i].prim0].xform;
-        const uint64_t nt = nodes[i].prim1 != RT_NONE ? 2 : 1;
-        bool found = false;
-        for (auto& e : per_xf) if (e.first == xf) { e.second += nt; found = true; break; }
-        if (!found) { if (per_xf.size() >= 64) continue; per_xf.push_back({xf, nt}); }
-    }
+    for (uint32_t i = h.root_node; i < h.root_end; ++i)
+        for (uint32_t p : {nodes[i].prim0, nodes[i].prim1}) {
+            if (p == RT_NONE || !coverable(geom[p].kind)) continue;
+            const uint32_t xf = geom[p].xform;
+            bool found = false;
+            for (auto& e : per_xf) if (e.first == xf) { e.second += 1; found = true; break; }
+            if (!found && per_xf.size() < 64) per_xf.push_back({xf, 1});
+        }
     uint64_t best = 0;
     for (auto& e : per_xf) if (e.second > best) { best = e.second; R.xf = e.first; }
     if (best < RT_PRUNE_MIN_TRIS) return;
-    // per leaf: are all its triangles well-shaped, and the box of their vertices in their own space
+    // per leaf: can every primitive be covered, and the box of the leaf's primitives in their own space
     const uint32_t n0 = h.root_node, n1 = h.root_end;
     std::vector<uint8_t> ok((size_t)(n1 - n0), 0);
     std::vector<double> box((size_t)(n1 - n0) * 6);
@@ -1579,15 +1583,45 @@ static void build_prune(const rt_blob_header& h, const rt_node* nodes, const rt_
     struct Key { int64_t k[3]; bool operator<(const Key& o) const { return std::lexicographical_compare(k, k + 3, o.k, o.k + 3); } };
     struct Item { Key first; std::array<double, 3> second, v0; uint32_t node; };
     std::vector<Item> keyed;
+    double sph_radius = 0.0;  // max over covered spheres of |centre|_inf + |radius|
+    uint64_t n_sph = 0;
+    // moving spheres are boxed over the camera's shutter; a ray with a time outside it is walked without pruning
+    const double Ta = std::min(h.camera.time0, h.camera.time1), Tb = std::max(h.camera.time0, h.camera.time1);
     for (uint32_t i = n0; i < n1; ++i) {
         const rt_node& nd = nodes[i];
-        if (!is_tri2(nd) || geom[nd.prim0].xform != R.xf) continue;
+        if (nd.prim0 == RT_NONE) continue;
         bool good = true;
         double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         std::array<double, 3> nh[2], vz[2]; int nn = 0;
-        double smin = 1.0, emax = 0.0, vmax = 0.0;
+        double smin = 1.0, emax = 0.0, vmax = 0.0, rad = 0.0;
+        uint32_t nsph_here = 0; bool moving_here = false;
         for (uint32_t p : {nd.prim0, nd.prim1}) {
             if (p == RT_NONE) continue;
+            if (geom[p].xform != R.xf || !coverable(geom[p].kind)) { good = false; break; }
+            if (geom[p].kind != RT_PRIM_TRIANGLE) {
+                // Sphere (shape.rs:93-121, moving: 202-247): an accepted hit needs a computed discriminant >= 0; its error against
+                // |d|^2 (r^2 - rho^2) (rho = distance of the centre from the ray's line) is below 24 u |d|^2 (|o - c|^2 + r^2), so the
+                // line passes within 2^-24 (|o - c|_2 + |r|) <= 2^-23 (|o|_inf + |c|_inf + |r|) of the ball: covered by tau (tau_coef >= 2^-21).
+                const bool mv = geom[p].kind == RT_PRIM_MOVING_SPHERE;
+                const double r = std::fabs(geom[p].d[mv ? 8 : 3]);
+                good = good && r >= 0x1p-100 && r <= 0x1p100;
+                double ends[2][3];
+                for (int k = 0; k < 3 && good; ++k) {
+                    if (mv) {  // centre(time) = c0 + (c1 - c0) ((time - t0) / (t1 - t0)), linear: the shutter's end points bound it
+                        const double c0 = geom[p].d[k], c1 = geom[p].d[3 + k], t0 = geom[p].d[6], t1 = geom[p].d[7];
+                        ends[0][k] = c0 + (c1 - c0) * ((Ta - t0) / (t1 - t0)); ends[1][k] = c0 + (c1 - c0) * ((Tb - t0) / (t1 - t0));
+                    } else ends[0][k] = ends[1][k] = geom[p].d[k];
+                    for (int e = 0; e < 2; ++e) {
+                        good = good && std::isfinite(ends[e][k]) && std::fabs(ends[e][k]) <= 0x1p100;
+                        const double slack = 0x1p-40 * (std::fabs(ends[e][k]) + r);  // rounding of the centre at the ray's time
+                        lo[k] = std::min(lo[k], std::nextafter(ends[e][k] - r - slack, -INFINITY)); hi[k] = std::max(hi[k], std::nextafter(ends[e][k] + r + slack, INFINITY));
+                        rad = std::max(rad, std::fabs(ends[e][k]) + r);
+                    }
+                }
+                if (!good) break;
+                ++nsph_here; moving_here = moving_here || mv;
+                continue;
+            }
             const double* v0 = geom[p].d; const double* e1 = geom[p].d + 3; const double* e2 = geom[p].d + 6;
             for (int k = 0; k < 9; ++k) good = good && std::isfinite(geom[p].d[k]);
             const double E1 = std::fabs(e1[0]) + std::fabs(e1[1]) + std::fabs(e1[2]), E2 = std::fabs(e2[0]) + std::fabs(e2[1]) + std::fabs(e2[2]);
@@ -1615,6 +1649,7 @@ static void build_prune(const rt_blob_header& h, const rt_node* nodes, const rt_
         ok[i - n0] = 1;
         for (int k = 0; k < 3; ++k) { box[(size_t)(i - n0) * 6 + 2 * k] = lo[k]; box[(size_t)(i - n0) * 6 + 2 * k + 1] = hi[k]; }
         shape_min = std::min(shape_min, smin); e_max = std::max(e_max, emax); v_max = std::max(v_max, vmax);
+        sph_radius = std::max(sph_radius, rad); n_sph += nsph_here; R.has_moving = R.has_moving || moving_here;
         R.n_tris += (uint64_t)nn;
         for (int t = 0; t < nn; ++t) {
             Key key;
@@ -1646,7 +1681,8 @@ static void build_prune(const rt_blob_header& h, const rt_node* nodes, const rt_
             babs = std::max(babs, std::max(std::fabs(lo), std::fabs(hi)));
         }
     }
-    if (R.n_prunable_nodes == 0 || keyed.empty()) return;
+    if (R.n_prunable_nodes == 0 || (keyed.empty() && n_sph == 0)) return;
+    R.n_tris += n_sph;  // primitives covered
     // distinct normals: members of a cluster differ from its representative by < 2^-33 per component
     std::sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
     // ... and, per cluster, the sorted offsets v0 . n^ of its members' planes (second stage of the certificate)
@@ -1669,6 +1705,7 @@ static void build_prune(const rt_blob_header& h, const rt_node* nodes, const rt_
         }
         flush();
         R.plane_off.push_back((uint32_t)R.planes.size());
+        if (keyed.empty()) R.plane_off.assign(1, 0u);
     }
     const size_t M = R.normals.size() / 3;
     if (M > RT_CERT_MAX_NORMALS) { R.normals.clear(); return; }
@@ -1697,9 +1734,10 @@ static void build_prune(const rt_blob_header& h, const rt_node* nodes, const rt_
         for (uint32_t e = fill[c]; e < R.cell_off[c + 1]; ++e) R.entries[e] = R.entries[fill[c] - 1];
     // tau = tau_coef (|o|_inf + radius) bounds the distance between the ray point the reference accepts and the triangle
     R.shape_min = shape_min;
-    R.tau_coef = 0x1p-21 / shape_min;
+    R.tau_coef = 0x1p-21 / shape_min;   // >= 2^-21: also covers the spheres' 2^-23
     R.delta_coef = 0x1p-20 / shape_min;
-    R.radius = v_max + e_max;
+    R.radius = std::max(v_max + e_max, sph_radius);
+    R.time0 = R.has_moving ? Ta : -INFINITY; R.time1 = R.has_moving ? Tb : INFINITY;
     R.box_abs_max = babs;
     R.on = true;
 }
@@ -1853,7 +1891,7 @@ static int prepare_scene(const void* blob, uint64_t nbytes, ScenePrep& P) {
         if (nd.prim0 == RT_NONE || geom[nd.prim0].kind != RT_PRIM_SPHERE) return false;
         return nd.prim1 == RT_NONE || (geom[nd.prim1].kind == RT_PRIM_SPHERE && geom[nd.prim0].xform == geom[nd.prim1].xform);
     };
-    build_prune(h, nodes, geom, is_tri2, P.prune);
+    build_prune(h, nodes, geom, is_tri2, is_sph2, P.prune);
     // ranges: the scene-level array and every instance sub-array (validated above: disjoint, links stay inside);
     // range_end[i] = end index of the range node i belongs to, ends_here[e] = some range ends before node e
     std::vector<uint32_t> range_end((size_t)h.n_nodes, h.n_nodes);
@@ -2043,13 +2081,13 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
         if (e == hipSuccess) e = hipMemcpy(sc->d_cert_cells, pr.cell_off.data(), pr.cell_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMalloc((void**)&sc->d_cert_entries, std::max<size_t>(pr.entries.size(), 1) * sizeof(CertEntry));
         if (e == hipSuccess) e = hipMemcpy(sc->d_cert_entries, pr.entries.data(), pr.entries.size() * sizeof(CertEntry), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMalloc((void**)&sc->d_cert_normals, pr.normals.size() * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void**)&sc->d_cert_normals, std::max<size_t>(pr.normals.size(), 1) * sizeof(double));
         if (e == hipSuccess) e = hipMemcpy(sc->d_cert_normals, pr.normals.data(), pr.normals.size() * sizeof(double), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMalloc((void**)&sc->d_cert_planes, pr.planes.size() * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void**)&sc->d_cert_planes, std::max<size_t>(pr.planes.size(), 1) * sizeof(double));
         if (e == hipSuccess) e = hipMemcpy(sc->d_cert_planes, pr.planes.data(), pr.planes.size() * sizeof(double), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMalloc((void**)&sc->d_cert_plane_off, pr.plane_off.size() * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMemcpy(sc->d_cert_plane_off, pr.plane_off.data(), pr.plane_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMalloc((void**)&sc->d_cert_plane_leaf, pr.plane_leaf.size() * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&sc->d_cert_plane_leaf, std::max<size_t>(pr.plane_leaf.size(), 1) * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMemcpy(sc->d_cert_plane_leaf, pr.plane_leaf.data(), pr.plane_leaf.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     }
     if (e != hipSuccess) {
@@ -2077,7 +2115,7 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     v.stream = sc->d_stream; v.root_off = P.root_off;
     v.node_off = sc->d_node_off; v.box_abs_max = box_abs_max;
     v.cert_cells = sc->d_cert_cells; v.cert_entries = sc->d_cert_entries; v.cert_normals = sc->d_cert_normals;
-    v.cert_planes = sc->d_cert_planes; v.cert_plane_off = sc->d_cert_plane_off; v.cert_plane_leaf = sc->d_cert_plane_leaf; v.prune_delta_coef = pr.delta_coef;
+    v.cert_planes = sc->d_cert_planes; v.cert_plane_off = sc->d_cert_plane_off; v.cert_plane_leaf = sc->d_cert_plane_leaf; v.cert_n_normals = (uint32_t)(pr.normals.size() / 3); v.prune_time0 = pr.time0; v.prune_time1 = pr.time1; v.prune_delta_coef = pr.delta_coef;
     v.prune_on = pr.on ? 1u : 0u; v.prune_xf = pr.xf;
     v.prune_tau_coef = pr.tau_coef; v.prune_radius = pr.radius; v.prune_box_abs_max = pr.box_abs_max;
     v.n_nodes = h.n_nodes; v.boxes_finite = boxes_finite ? 1u : 0u;

@@ -37,7 +37,8 @@ struct SceneDev {
     const uint32_t* cert_plane_off;  // [n_normals + 1] CSR offsets into cert_planes
     const uint32_t* cert_plane_leaf; // parallel to cert_planes: stream offset of the triangle's leaf record
     double prune_tau_coef, prune_delta_coef, prune_radius, prune_box_abs_max;
-    uint32_t prune_on, prune_xf;
+    double prune_time0, prune_time1;  // covered moving spheres are boxed over this shutter; rays outside it are not pruned
+    uint32_t prune_on, prune_xf, cert_n_normals;
     uint32_t root_off;  // first scene-level record in `stream` (the range is closed by an END record)
     rt_camera camera;
     uint32_t n_lights, root_node, root_end, background;

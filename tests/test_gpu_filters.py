@@ -221,3 +221,34 @@ def test_strict_pruning_on_the_pagoda_with_surface_and_plane_rays(gpu_ctx):
     assert (o[0] != rt.NONE).sum() > n // 3
     pr = _plane_rays(tris, rng, n); pr[:, :3] += 5.0
     _check(gpu_ctx, text, pr)
+
+
+def test_strict_pruning_of_spheres_and_moving_spheres(gpu_ctx):
+    # the random scene (main.rs:365-494) is spheres and moving spheres only: every inner node is prunable, no certificate needed.
+    # Grazing rays (distance from the centre = r (1 + eps), eps down to 0) put the discriminant of shape.rs:93-121 at its rounding
+    # error; times outside the camera's shutter must switch pruning off, not move a sphere out of its box.
+    hs = rt.HostScene.builtin("random", bvh_seed=3)
+    info = hs.prune_info()
+    assert info["on"] == 1.0 and info["normals"] == 0.0
+    text = hs.describe()
+    geo = hs.geoms()
+    rng = np.random.default_rng(41)
+    n = 6000
+    k = rng.integers(0, len(geo), n)
+    tm = rng.uniform(0.0, 1.0, n)
+    tm[::5] = rng.uniform(-0.5, 1.5, len(tm[::5]))
+    mv = geo["kind"][k] == 2
+    d = geo["d"][k]
+    frac = np.where(mv, (tm - d[:, 6]) / np.where(mv, d[:, 7] - d[:, 6], 1.0), 0.0)
+    c = np.where(mv[:, None], d[:, 0:3] + (d[:, 3:6] - d[:, 0:3]) * frac[:, None], d[:, 0:3])
+    r = np.abs(np.where(mv, d[:, 8], d[:, 3]))
+    dirs = rng.normal(size=(n, 3)); dirs /= np.linalg.norm(dirs, axis=1)[:, None]
+    perp = np.cross(dirs, rng.normal(size=(n, 3))); perp /= np.linalg.norm(perp, axis=1)[:, None]
+    eps = 10.0 ** rng.uniform(-16, -3, n) * rng.choice([-1, 1], n); eps[::4] = 0.0
+    p = c + perp * (r * (1 + eps))[:, None]                       # point of closest approach, at r (1 + eps) from the centre
+    rays = np.zeros((n, 7)); rays[:, :3] = p - dirs * rng.uniform(0.5, 30, n)[:, None]; rays[:, 3:6] = dirs * 10.0 ** rng.uniform(-3, 3, n)[:, None]; rays[:, 6] = tm
+    o = _check(gpu_ctx, text, rays)
+    assert 0 < (o[0] != rt.NONE).sum()
+    org = rng.uniform(-15, 15, (n, 3)); org[:, 1] = rng.uniform(0.1, 8, n)
+    rnd = _rays_at(rng.uniform(-11, 11, (n, 3)) * np.array([1, 0.1, 1]), org); rnd[:, 6] = rng.uniform(0, 1, n)
+    _check(gpu_ctx, text, rnd)

@@ -257,23 +257,36 @@ def test_local_boxes_contain_the_triangles_below_them(name):
         sub = range(i + 1, int(nodes[i]["skip"]))
         leaves = [j for j in sub if nodes[j]["prim0"] != rt.NONE]
         prims = [int(p) for j in leaves for p in (nodes[j]["prim0"], nodes[j]["prim1"]) if p != rt.NONE]
-        all_tri = bool(prims) and all(geo[p]["kind"] == 0 and geo[p]["xform"] == int(info["xform"]) for p in prims)
+        # coverable: triangles, spheres and moving spheres of the pruned space
+        all_cov = bool(prims) and all(geo[p]["kind"] in (0, 1, 2) and geo[p]["xform"] == int(info["xform"]) for p in prims)
         if not np.isfinite(lb).all():
             assert (lb[:, 0] == -inf).all() and (lb[:, 1] == inf).all()      # never pruned
-            # ... and there is a reason: pruning off, an instance range, or something other than a triangle of the space below
-            assert (not info["on"]) or i >= h.root_end or not all_tri
+            # ... and there is a reason: pruning off, an instance range, or something that cannot be covered below
+            assert (not info["on"]) or i >= h.root_end or not all_cov
             continue
         n_finite += 1
-        assert info["on"] and i < h.root_end and all_tri
-        d = geo["d"][prims]
-        verts = np.concatenate([d[:, 0:3], d[:, 0:3] + d[:, 3:6], d[:, 0:3] + d[:, 6:9]])
+        assert info["on"] and i < h.root_end and all_cov
+        pts = []
+        for p in prims:
+            d = geo["d"][p]
+            if geo[p]["kind"] == 0:
+                pts += [d[0:3], d[0:3] + d[3:6], d[0:3] + d[6:9]]
+            elif geo[p]["kind"] == 1:
+                pts += [d[0:3] - abs(d[3]), d[0:3] + abs(d[3])]
+            else:   # moving sphere: centre at both ends of the camera's shutter
+                for tm in (h.camera.time0, h.camera.time1):
+                    c = d[0:3] + (d[3:6] - d[0:3]) * ((tm - d[6]) / (d[7] - d[6]))
+                    pts += [c - abs(d[8]), c + abs(d[8])]
+        verts = np.array(pts)
         assert (verts >= lb[:, 0]).all() and (verts <= lb[:, 1]).all()        # the fp32 box is rounded outward
         assert (verts.min(0) - lb[:, 0] <= 1e-6 * (1 + np.abs(lb[:, 0]))).all() and (lb[:, 1] - verts.max(0) <= 1e-6 * (1 + np.abs(lb[:, 1]))).all()  # and tight
     assert n_finite == int(info["prunable_nodes"])
     if name in ("mesh", "soup", "soup_scaled"):
         assert info["on"] and n_finite > 0.4 * (nodes["prim0"] == rt.NONE).sum()
-    if name in ("cornell", "random", "simple_triangle"):
-        assert not info["on"]                                                  # instances only / spheres only / 10 triangles
+    if name == "random":
+        assert info["on"] and n_finite == (nodes["prim0"] == rt.NONE).sum()    # spheres and moving spheres: every inner node
+    if name in ("cornell", "simple_triangle"):
+        assert not info["on"]                                                  # instances only / 10 triangles
 
 
 def test_certificate_is_conservative_on_the_pagoda():
