@@ -2,13 +2,13 @@
 //
 // Pipeline (one "pass" = every pixel x samples_per_pass camera samples in flight):
 //   k_raygen  -> [ k_trace(path rays) -> k_shade -> k_trace(shadow rays) ] x max_depth -> k_unwind -> k_accumulate
-// * k_trace is a WAVE-COHERENT threaded-BVH walk: the 64 rays of a wave advance through the
-//   pre-order node array together; the node index is wave-uniform, so nodes / primitives / vertices
-//   arrive by scalar loads (one fetch per wave) and all 64 lanes spend their VALU slots on the f64
-//   slab / Moller-Trumbore arithmetic.  Each lane keeps only "the next node I need" (its private
-//   skip target); the wave jumps to the minimum over lanes.  The order in which a lane sees nodes,
-//   and the t_max it carries, are exactly the reference recursion's (bvh.rs:91-106), so the closest
-//   hit (primitive, t) is bit-identical by construction.
+// * k_trace is a WAVE-COHERENT walk of the trace stream (the threaded pre-order BVH re-packed into filter records): the 64
+//   rays of a wave advance through it together; the cursor is wave-uniform, so records arrive by scalar loads (one fetch
+//   per wave).  Each lane keeps only "the next record I need" (its private skip target).  Every test is first classified
+//   by an fp32 filter with a proven error bound and only undecided lanes run the reference's f64 arithmetic; subtrees that
+//   provably hold no triangle / sphere the reference would ACCEPT are skipped (strict pruning).  A lane tests a subset of
+//   the primitives the reference tests, in the reference's order (bvh.rs:91-106) with the reference's running t_max, and
+//   never skips an accepted one: the closest hit (primitive, t) is bit-identical (DESIGN.md section 5 has the argument).
 // * k_shade evaluates one ray_colour level (integrator.rs) per live path, writes a bounce record,
 //   the next ray and (MIS) the shadow ray, and compacts survivors into the next queue with a
 //   wave64 ballot + popcount prefix and ONE atomic per wave.
@@ -855,7 +855,7 @@ RT_DEV void traverse(const SceneDev& sc, uint32_t first, const RAYSRC& src, HIT&
 #ifndef RT_TRACE_WAVES_REGS
 #define RT_TRACE_WAVES_REGS 3
 #endif
-// rays: SoA [7][cap] (ox,oy,oz,dx,dy,dz,time) indexed by path; outputs indexed by path.
+// rays: one 64-byte block per path (ox,oy,oz,dx | dy,dz,time,pad); outputs indexed by path.
 // REGS: keep the f64 ray in registers instead of LDS -- for scenes whose leaves are mostly not triangles, where
 // (almost) every leaf step runs an exact f64 test and would read the ray back from LDS each time.
 template <bool COUNT, bool INST, bool REGS>
@@ -1032,7 +1032,7 @@ RT_DEV uint32_t sort_key(const SceneDev& sc, d3 o, d3 d) {
     return ((morton >> 9) << 18) | (oct << 15) | ((morton & 0x1FFu) << 6) | dbin;
 #endif
 }
-#define RT_SORT_BITS 25u  /* 24 key bits + bit 24 = "empty slot" (slots are pre-filled with 0xFFFFFFFF) */
+#define RT_SORT_BITS 25u  /* 24 key bits (+ one spare): octant | origin cell | direction bin */
 
 RT_DEV void push_queue_keyed(bool want, uint32_t path, uint32_t key, uint32_t* __restrict__ queue, uint32_t* __restrict__ keys, uint32_t* __restrict__ count) {
     const uint64_t m = __ballot(want);
@@ -1410,7 +1410,7 @@ static void launch_trace(rt_scene* sc, bool count, const uint32_t* queue, const 
 
 // Runs the wavefront loop for n paths whose (pixel, sample) come either from explicit device lists
 // (ws.in_pixel / ws.in_sample) or from the frame formula; leaves per-path radiance in ws.pb.radiance.
-// stable LSD radix sort of (key, path) over the n slots of a queue; empty slots carry 0xFFFFFFFF and end up last
+// stable LSD radix sort of the n live (key, path) pairs of a queue
 static int sort_queue(rt_scene* sc, uint32_t n, uint32_t* keys_in, uint32_t* queue_in, uint32_t* out_queue) {
     Workspace& ws = sc->ws;
     size_t bytes = ws.sort_tmp_bytes;
