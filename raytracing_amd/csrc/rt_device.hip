@@ -586,7 +586,7 @@ RT_DEV lanemask box_step(const Window& w, const BoxFilter& bf, const PruneState&
     lanemask m_pass;
     if (MODE == BOX_PLAIN) {
         lanemask cp = 0ull, cf = 0ull, sp = 0ull;
-        if (strict && ps.enable != 0ull) {
+        if (strict && ps.enable != 0ull && wword<B + 8>(w) != 0xFF800000u) {  // a local box starting at -inf is the (-inf, +inf) box of a subtree that is never pruned
             sp = strict_filter<B + 8>(ps.sf, w) & ps.enable;
             if (ps.any_suspect) {  // a subtree that holds one of the ray's suspect leaves is not pruned
                 const uint32_t span = wword<B + 6>(w) - off;
