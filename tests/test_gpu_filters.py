@@ -252,3 +252,43 @@ def test_strict_pruning_of_spheres_and_moving_spheres(gpu_ctx):
     org = rng.uniform(-15, 15, (n, 3)); org[:, 1] = rng.uniform(0.1, 8, n)
     rnd = _rays_at(rng.uniform(-11, 11, (n, 3)) * np.array([1, 0.1, 1]), org); rnd[:, 6] = rng.uniform(0, 1, n)
     _check(gpu_ctx, text, rnd)
+
+
+def test_strict_pruning_next_to_instances_mixed_leaves_and_rectangles(gpu_ctx):
+    # the nested-walk kernel variant with pruning on: a triangle soup (pruned space = world), spheres and moving spheres in
+    # the same space (covered), an instanced cube BVH under a transform, a rectangle and a sphere under another transform
+    # (their ancestors are never pruned)
+    rng = np.random.default_rng(51)
+    s = SceneText(bvh_seed=6)
+    m = s.lambertian_rgb(.5, .5, .5)
+    verts, faces = [], []
+    for k in range(150):
+        c = rng.uniform(-4, 4, 3)
+        for _ in range(3):
+            verts.append(tuple(c + rng.normal(size=3) * 0.35))
+        faces.append((3 * k, 3 * k + 1, 3 * k + 2))
+    me = s.mesh(verts, [(0, 0, 1)] * len(verts), [(0, 0)] * len(verts), faces, m)
+    ids = [s.triangle(me, k) for k in range(150)]
+    for k in range(30):
+        c = rng.uniform(-4, 4, 3)
+        ids.append(s.sphere(tuple(c), float(rng.uniform(0.1, 0.5)), m) if k % 2 else
+                   s.moving_sphere(tuple(c), tuple(c + rng.normal(size=3) * 0.3), 0.0, 1.0, float(rng.uniform(0.1, 0.4)), m))
+    cube_v = [(x, y, z) for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)]
+    cube_f = [(0, 1, 3), (0, 3, 2), (4, 6, 7), (4, 7, 5), (0, 4, 5), (0, 5, 1), (2, 3, 7), (2, 7, 6), (0, 2, 6), (0, 6, 4), (1, 5, 7), (1, 7, 3)]
+    cm = s.mesh(cube_v, [(0, 0, 1)] * 8, [(0, 0)] * 8, cube_f, m)
+    cube = s.bvh([s.triangle(cm, k) for k in range(12)])
+    ids.append(s.transformed(s.xform(translate(2.0, 1.0, -1.0)), cube))
+    ids.append(s.aarect(-2, 2, -2, 2, -3.0, m))
+    ids.append(s.transformed(s.xform(scale(1.3, 0.7, 1.1)), s.sphere((1.0, -2.0, 0.5), 0.6, m)))
+    text = s.finish(ids, build_bvh=True)
+    hs = rt.HostScene.from_description(text)
+    info = hs.prune_info()
+    assert info["on"] == 1.0 and 0 < info["prunable_nodes"] < (hs.nodes()["prim0"] == rt.NONE).sum()
+    n = 6000
+    org = rng.uniform(-9, 9, (n, 3)); tgt = rng.uniform(-4, 4, (n, 3))
+    rays = _rays_at(tgt, org); rays[:, 6] = rng.uniform(-0.2, 1.2, n)
+    o = _check(gpu_ctx, text, rays)
+    assert (o[0] != rt.NONE).sum() > n // 5 and (o[1] != rt.NONE).sum() > 0      # some hits inside the instance
+    tris = np.array(verts).reshape(150, 3, 3)
+    pr = _plane_rays(tris, rng, n); pr[:, 6] = rng.uniform(0, 1, n)
+    _check(gpu_ctx, text, pr)
