@@ -135,6 +135,7 @@ def main():
                                   seed=0x5EED, flags=rt.RENDER_COUNT_TESTS).as_dict()
         r1 = max(scratch_stats["rays"], 1)
         n_box, n_tri, n_sph = scratch_stats["box_tests"] / r1, scratch_stats["tri_tests"] / r1, scratch_stats["sphere_tests"] / r1
+        wave_steps = sum(s["trace_wave_steps"] for s in stats)
         ms_trace = sum(s["ms_trace"] for s in stats)
         launches = max(sum(s["trace_launches"] for s in stats), 1)
         avg_launch_s = ms_trace / launches / 1e3
@@ -170,7 +171,11 @@ def main():
                                  "untimed pass of the counting kernel; the production kernel skips every subtree whose triangle box the ray's line provably "
                                  "misses (strict pruning, DESIGN.md 5) and serves the rest from the scalar cache / L2, so this ratio is the algorithmic "
                                  "saving, not a bandwidth claim; the kernel's own bound is VALU issue (issue_pmc: rocprofv3 counters of the committed profile)",
-                         "issue_pmc": pmc},
+                         "issue_pmc": pmc,
+                         # what the production kernel executed in the timed passes: stream records stepped through per wave of 64 rays
+                         # (one record = one box or leaf filter for the wave); 160 B = the scalar load window fetched per step
+                         "executed": {"record_steps_per_ray": wave_steps / max(rays, 1), "reference_tests_per_ray": n_box + n_tri + n_sph,
+                                      "scalar_window_bytes_per_ray": 136.0 * wave_steps / max(rays, 1)}},
             "roofline_valu": {"bound": "valu_f64", "achieved": flops_per_ray * rays_per_launch / avg_launch_s / 1e12, "peak": VALU_F64_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": flops_per_ray * rays_per_launch / avg_launch_s / 1e12 / VALU_F64_PEAK_TFLOPS,
                               "flops_per_ray": flops_per_ray},

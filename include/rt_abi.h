@@ -179,6 +179,7 @@ typedef struct rt_stats {
     double ms_shade;     /* sum over shade launches */
     double ms_other;     /* raygen + unwind/accumulate + queue upkeep */
     uint64_t trace_launches;
+    uint64_t trace_wave_steps;  /* stream records stepped through, summed over the waves of every traversal launch (one record = one box or leaf test for up to 64 rays) */
     uint64_t filter_violations; /* only with RT_RENDER_COUNT_TESTS: fp32 filter decisions contradicted by the exact f64 test; 0 by construction */
 } rt_stats;
 

@@ -23,7 +23,7 @@ class RenderParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays", u64), ("paths", u64), ("box_tests", u64), ("tri_tests", u64), ("sphere_tests", u64),
                 ("launches", u64), ("ms_total", f64), ("ms_trace", f64), ("ms_shade", f64), ("ms_other", f64),
-                ("trace_launches", u64), ("filter_violations", u64)]
+                ("trace_launches", u64), ("trace_wave_steps", u64), ("filter_violations", u64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -87,6 +87,7 @@ typedef LaneHitT<RegCell> LaneHitRegs;  // scenes whose leaf steps are exact tes
 struct LaneCount {
     uint32_t box, tri, sph;
     uint32_t bad;  // COUNT variant only: filter decisions contradicted by the exact test (must stay 0)
+    uint32_t wsteps;  // records this wave stepped through (wave-uniform; summed into stats[15])
     uint32_t pruned_until, uncertified;  // COUNT variant only: end of the subtree strict pruning would have skipped; ray walked without certificate
 #ifdef RT_TRACE_DIAG  // diagnostic build only (make diag): wave-level step counts and s_memtime cycle stamps
     uint64_t steps, leaf_steps, cyc_wait, cyc_total, lane_steps, exact_box, exact_tri;
@@ -722,6 +723,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
             window_wait(w);
             const uint32_t skip = wword<6>(w), rec = wword<7>(w);
             const uint32_t node = rec >> 8;
+            cnt.wsteps += 1u;
 #ifdef RT_TRACE_DIAG
             cnt.cyc_wait += __builtin_readcyclecounter() - c0; cnt.steps += 1; cnt.leaf_steps += (rec & RT_STREAM_KIND) ? 1u : 0u;
 #endif
@@ -753,6 +755,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
 #ifdef RT_TRACE_DIAG
                     cnt.steps += 1;
 #endif
+                    cnt.wsteps += 1u;
                     m_pass = box_step<16, MODE, COUNT>(w, bf, ps, true, off, wait, rec2, nodes, src, h, t_min, cnt);
                     off = m_pass == 0ull ? wword<22>(w) : off + RT_STREAM_REC_INNER;
                 }
@@ -888,7 +891,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : 
     LaneHit h;
     h.best.p = (lptr<volatile double>)&lds_best[threadIdx.x]; h.prim.p = (lptr<volatile uint32_t>)&lds_prim[threadIdx.x]; h.inst.p = (lptr<volatile uint32_t>)&lds_inst[threadIdx.x];
     h.best = t_max; h.prim = RT_NONE; h.inst = RT_NONE;
-    LaneCount cnt; cnt.box = cnt.tri = cnt.sph = cnt.bad = 0; cnt.pruned_until = 0; cnt.uncertified = 0;
+    LaneCount cnt; cnt.box = cnt.tri = cnt.sph = cnt.bad = 0; cnt.pruned_until = 0; cnt.uncertified = 0; cnt.wsteps = 0;
 #ifdef RT_TRACE_DIAG
     cnt.steps = cnt.leaf_steps = cnt.cyc_wait = cnt.lane_steps = cnt.exact_box = cnt.exact_tri = 0; cnt.cyc_total = __builtin_readcyclecounter(); cnt.diag_flags = 0;
 #endif
@@ -916,6 +919,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : 
         atomicAdd(&stats[6], (unsigned long long)cnt.cyc_wait); atomicAdd(&stats[7], (unsigned long long)cnt.cyc_total); atomicAdd(&stats[8], 1ull);
     }
 #endif
+    if (stats && lane_id() == 0) atomicAdd(&stats[15], (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)cnt.wsteps));
     if (valid) {
         const uint32_t hp = h.prim;
         const double ht = hp != RT_NONE ? (double)h.best : __builtin_nan("");
@@ -2311,7 +2315,7 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
         stats->rays = st4[0]; stats->box_tests = st4[1]; stats->tri_tests = st4[2]; stats->sphere_tests = st4[3];
         stats->paths = (uint64_t)npix * spp; stats->launches = launches;
         stats->ms_total = ms; stats->ms_trace = by_cat[CAT_TRACE]; stats->ms_shade = by_cat[CAT_SHADE]; stats->ms_other = by_cat[CAT_OTHER];
-        stats->trace_launches = n_by_cat[CAT_TRACE]; stats->filter_violations = st4[13];
+        stats->trace_launches = n_by_cat[CAT_TRACE]; stats->filter_violations = st4[13]; stats->trace_wave_steps = st4[15];
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return RT_OK;
