@@ -324,3 +324,68 @@ def test_certificate_is_conservative_on_the_pagoda():
     in_plane = (np.abs(eta) < 2.0 ** -26) & (np.abs(off) < 1e-6)
     assert in_plane.sum() > 20 and (code_raw[N:][in_plane] != 1).all()   # rays lying in a triangle's plane never are
     assert (code_raw[N:] == 2).sum() > 0                     # and some of them walk with protected leaves
+
+
+def test_pruned_walk_over_the_stream_finds_the_oracles_hits():
+    # numpy emulation of the production walk on the CPU: pre-order records, the reference's per-axis test on the blob's boxes,
+    # PLUS skipping every inner record whose LOCAL box (from the stream) the ray's line misses by more than tau.  The hits must
+    # be the oracle's, with a small fraction of the records visited.
+    hs = rt.HostScene.builtin("mesh", bvh_seed=3)
+    osc = orc.OracleScene(hs.describe())
+    h, nodes, geo = hs.header(), hs.nodes(), hs.geoms()
+    info = hs.prune_info()
+    stream, _, node_off = hs.trace_stream()
+    raw = stream.tobytes()
+    rays = osc.primary_rays(48, 27, 0, 0x5EED)[::3]
+    n = len(rays)
+    o, d = rays[:, :3], rays[:, 3:6]
+    inv = 1.0 / d
+    ol = o - 5.0                                           # the pagoda's transform: translate(5, 5, 5), main.rs:816
+    tau = info["tau_coef"] * (np.abs(ol).max(1) + info["radius"])
+    best = np.full(n, 1e5); prim = np.full(n, rt.NONE, np.int64)
+    wait = np.zeros(n, np.int64)
+    visited = 0; full = 0
+    skip = nodes["skip"].astype(np.int64)
+    for i in range(h.root_end):
+        act = wait <= i
+        if not act.any():
+            continue
+        nd = nodes[i]
+        t0 = (nd["bmin"] - o) * inv; t1 = (nd["bmax"] - o) * inv
+        ok = (np.minimum(t0, t1).max(1) <= best) & (np.maximum(t0, t1).min(1) >= 0.001)     # bounding_box.rs:27-46 (no NaN here)
+        if nd["prim0"] == rt.NONE:
+            lb = np.array(struct.unpack_from("<6f", raw, int(node_off[i]) + 32), np.float64).reshape(3, 2)
+            if np.isfinite(lb).all():
+                a0 = (lb[:, 0] - tau[:, None] - ol) * inv; a1 = (lb[:, 1] + tau[:, None] - ol) * inv
+                b0 = (lb[:, 0] + tau[:, None] - ol) * inv; b1 = (lb[:, 1] - tau[:, None] - ol) * inv
+                near = np.minimum(np.minimum(a0, a1), np.minimum(b0, b1)).max(1); far = np.maximum(np.maximum(a0, a1), np.maximum(b0, b1)).min(1)
+                ok &= ~(near > far)                                                        # the line misses the inflated local box
+        visited += int(act.sum())
+        p = act & ok
+        wait[act & ~ok] = skip[i]
+        for pid in (int(nd["prim0"]), int(nd["prim1"])):
+            if pid == rt.NONE or not p.any():
+                continue
+            g = geo[pid]
+            if g["kind"] == 0:                                                             # mesh.rs:55-81
+                v0, e1, e2 = g["d"][:3], g["d"][3:6], g["d"][6:9]
+                hh = np.cross(d, e2); det = hh @ e1
+                with np.errstate(all="ignore"):
+                    f = 1.0 / det; s = ol - v0; u = f * (s * hh).sum(1); q = np.cross(s, e1); v = f * (d * q).sum(1); t = f * (q @ e2)
+                acc = p & ~((det > -2.2e-16) & (det < 2.2e-16)) & (u >= 0) & (u <= 1) & (v >= 0) & (u + v <= 1) & (t > 2.2e-16) & (t <= best) & (t > 0.001)
+            elif g["kind"] == 1:                                                           # shape.rs:93-121
+                c, r = g["d"][:3], g["d"][3]; oc = o - c; a = (d * d).sum(1); hb = (oc * d).sum(1); cc = (oc * oc).sum(1) - r * r
+                disc = hb * hb - a * cc
+                with np.errstate(all="ignore"):
+                    sq = np.sqrt(disc); ta = (-hb - sq) / a; tb = (-hb + sq) / a
+                first = ~((ta < 0.001) | (best < ta)); t = np.where(first, ta, tb)
+                acc = p & (disc >= 0) & ~((t < 0.001) | (best < t))
+            else:
+                continue
+            best = np.where(acc, t, best); prim = np.where(acc, pid, prim)
+    want_prim, _, want_t, cnt = osc.trace_closest(rays, 0.001, 1e5)
+    obj = np.where(prim == rt.NONE, rt.NONE, hs.prims()["object_id"][np.minimum(prim, h.n_prims - 1)])    # the oracle reports object ids
+    assert np.array_equal(obj.astype(np.uint32), want_prim)
+    hit = want_prim != rt.NONE
+    assert hit.sum() > n // 2 and np.allclose(best[hit], want_t[hit], rtol=1e-9)
+    assert visited < 0.05 * int(cnt[0])                    # a few percent of the reference's box tests
