@@ -158,3 +158,24 @@ def test_edge_cases(gpu_ctx):
     out = gs.sample_radiance(16, 9, [0, 50, 143], [0, 0, 0], 5, rt.INT_MIS, 1)
     assert (out > 0.4).all() and (out <= 1.0 + 1e-12).all()
     gs.close()
+
+
+@pytest.mark.parametrize("integ", [rt.INT_BRDF, rt.INT_MIS])
+def test_full_size_pruned_walk_equals_reference_order_walk(gpu_ctx, integ):
+    # BASELINE.json's full frame (pagoda, 1920x1080, depth 5): the production kernel (fp32 filters, strict pruning, ~1 % of
+    # the tests) and the counting kernel (the reference's complete visited set, every test in f64 beside its filter) must
+    # produce the SAME accumulator bit for bit -- every ray of every bounce got the same (primitive, t) -- with zero
+    # contradicted shortcuts; and rendering the frame twice is deterministic.  12-20 M rays per integrator.
+    hs = rt.HostScene.builtin("mesh", bvh_seed=3)
+    gs = gpu_ctx.upload(hs)
+    w, h = 1920, 1080
+    a, sa = gs.render_host(w, h, 0, 3, 5, integ, seed=0x5EED)
+    b, sb = gs.render_host(w, h, 0, 3, 5, integ, seed=0x5EED, flags=rt.RENDER_COUNT_TESTS)
+    c, _ = gs.render_host(w, h, 0, 3, 5, integ, seed=0x5EED)
+    gs.close()
+    sa, sb = sa.as_dict(), sb.as_dict()
+    assert sa["rays"] == sb["rays"] > 10_000_000
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(a.view(np.uint32), c.view(np.uint32))
+    assert sb["filter_violations"] == 0 and sb["box_tests"] > 4000 * sb["rays"]
+    assert sa["trace_wave_steps"] * 64 < 0.1 * sb["box_tests"]          # lane-records stepped through: a few percent of the reference's box tests
