@@ -203,9 +203,14 @@ int rt_scene_destroy(rt_scene* scene);
  * exists so that tests without a GPU can check what the kernel will walk. */
 int rt_stream_build_host(const void* blob, uint64_t nbytes, void* stream_out, uint64_t capacity, uint64_t* stream_bytes,
                          uint32_t* root_off, uint32_t* node_off);
+/* Same for the PRODUCTION stream the pruning kernel walks: inner nodes that can never be pruned and whose box holds
+ * everything that can be have no record (node_off gives their first child's offset).  DESIGN.md section 5. */
+int rt_stream_build_prod_host(const void* blob, uint64_t nbytes, void* stream_out, uint64_t capacity, uint64_t* stream_bytes,
+                              uint32_t* root_off, uint32_t* node_off);
 /* Host only, for tests without a GPU: what rt_scene_upload derives for strict pruning.
  * info[12] = enabled, pruned transform id, triangles covered, inner records with a local box, distinct normal
- * clusters, direction-grid entries, minimum shape factor, tau_coef, delta_coef, radius, local box |max|, 0.
+ * clusters, direction-grid entries, minimum shape factor, tau_coef, delta_coef, radius, local box |max|, inner nodes
+ * without a record in the production stream.
  * rays (may be NULL with n_rays = 0): n_rays x 6 doubles (origin, direction) ALREADY in the pruned space;
  * certified[i] = 1 iff the device would walk that ray with pruning.  No counterpart in the reference. */
 int rt_prune_info_host(const void* blob, uint64_t nbytes, double* info, uint32_t n_rays, const double* rays, uint8_t* certified);

@@ -82,14 +82,16 @@ class HostScene:
         b, h = self.blob(), self.header()
         return np.frombuffer(b, dtype=np.dtype([("d", "<f8", 9), ("kind", "<u4"), ("xform", "<u4")]), count=h.n_prims, offset=h.off_geom)
 
-    def trace_stream(self):
+    def trace_stream(self, production=False):
         """The device trace stream rt_scene_upload derives from this scene, built on the host (no GPU needed):
-        (stream bytes as uint8 array incl. padding, offset of the root record, record offset per node index)."""
+        (stream bytes as uint8 array incl. padding, offset of the root record, record offset per node index).
+        production=True: the form the pruning kernel walks (always-entered inner nodes have no record)."""
         b, h = self.blob(), self.header()
+        fn = _ffi.hip().rt_stream_build_prod_host if production else _ffi.hip().rt_stream_build_host
         n, root = _ffi.u64(), _ffi.u32()
-        _hip_check(_ffi.hip().rt_stream_build_host(b, len(b), None, 0, C.byref(n), C.byref(root), None))
+        _hip_check(fn(b, len(b), None, 0, C.byref(n), C.byref(root), None))
         out = np.zeros(n.value, np.uint8); off = np.zeros(h.n_nodes + 1, np.uint32)
-        _hip_check(_ffi.hip().rt_stream_build_host(b, len(b), out.ctypes.data, out.nbytes, C.byref(n), C.byref(root), off.ctypes.data))
+        _hip_check(fn(b, len(b), out.ctypes.data, out.nbytes, C.byref(n), C.byref(root), off.ctypes.data))
         return out, int(root.value), off
 
     def prune_info(self, rays=None):
@@ -101,7 +103,7 @@ class HostScene:
         r = np.ascontiguousarray(rays, np.float64) if n else np.zeros((1, 6))
         cert = np.zeros(max(n, 1), np.uint8)
         _hip_check(_ffi.hip().rt_prune_info_host(b, len(b), info.ctypes.data, n, r.ctypes.data, cert.ctypes.data))
-        keys = ("on", "xform", "triangles", "prunable_nodes", "normals", "grid_entries", "shape_min", "tau_coef", "delta_coef", "radius", "box_abs_max")
+        keys = ("on", "xform", "triangles", "prunable_nodes", "normals", "grid_entries", "shape_min", "tau_coef", "delta_coef", "radius", "box_abs_max", "elided_nodes")
         d = dict(zip(keys, info))
         return (d, cert[:n].copy()) if rays is not None else d
 

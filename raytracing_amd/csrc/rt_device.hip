@@ -402,7 +402,7 @@ struct Suspects {
     }
 };
 // second stage for one listed cluster: exact direction test, then the distance of the origin from the cluster's planes
-RT_DEV void cluster_suspects(const SceneDev& sc, uint32_t c, d3 o, d3 d, double thr, double delta, Suspects& sus) {
+RT_DEV void cluster_suspects(const SceneDev& sc, const uint32_t* __restrict__ node_off, uint32_t c, d3 o, d3 d, double thr, double delta, Suspects& sus) {
     const double* __restrict__ n = sc.cert_normals + 3u * (size_t)c;
     if (fabs(d.x * n[0] + d.y * n[1] + d.z * n[2]) >= thr) return;
     // Nearly parallel to the planes of this cluster.  The reference can only accept such a triangle if the origin
@@ -416,10 +416,10 @@ RT_DEV void cluster_suspects(const SceneDev& sc, uint32_t c, d3 o, d3 d, double 
         const uint32_t mid = (lo + hi) >> 1;
         if (pl[mid] < q - delta) lo = mid + 1; else hi = mid;
     }
-    for (; lo < last && !(pl[lo] > q + delta) && !sus.overflow; ++lo) sus.add(leaf[lo]);
+    for (; lo < last && !(pl[lo] > q + delta) && !sus.overflow; ++lo) sus.add(node_off[leaf[lo]]);  // the leaf's record in the stream being walked
 }
 // false: the ray must be walked without pruning
-RT_DEV bool ray_certified(const SceneDev& sc, d3 o, d3 d, Suspects& sus) {
+RT_DEV bool ray_certified(const SceneDev& sc, const uint32_t* __restrict__ node_off, d3 o, d3 d, Suspects& sus) {
 #pragma unroll
     for (int k = 0; k < RT_SUSPECT_SLOTS; ++k) sus.leaf[k] = 0xFFFFFFFFu;
     sus.overflow = false;
@@ -446,10 +446,10 @@ RT_DEV bool ray_certified(const SceneDev& sc, d3 o, d3 d, Suspects& sus) {
         const float m0 = fabsf(fx * e0.x + fy * e0.y + fz * e0.z), m1 = fabsf(fx * e1.x + fy * e1.y + fz * e1.z);
         const float m2 = fabsf(fx * e2.x + fy * e2.y + fz * e2.z), m3 = fabsf(fx * e3.x + fy * e3.y + fz * e3.z);
         if (!(fminf(fminf(m0, m1), fminf(m2, m3)) >= thr32)) {
-            if (!(m0 >= thr32)) cluster_suspects(sc, __builtin_bit_cast(uint32_t, e0.w), o, d, thr, delta, sus);
-            if (!(m1 >= thr32)) cluster_suspects(sc, __builtin_bit_cast(uint32_t, e1.w), o, d, thr, delta, sus);
-            if (!(m2 >= thr32)) cluster_suspects(sc, __builtin_bit_cast(uint32_t, e2.w), o, d, thr, delta, sus);
-            if (!(m3 >= thr32)) cluster_suspects(sc, __builtin_bit_cast(uint32_t, e3.w), o, d, thr, delta, sus);
+            if (!(m0 >= thr32)) cluster_suspects(sc, node_off, __builtin_bit_cast(uint32_t, e0.w), o, d, thr, delta, sus);
+            if (!(m1 >= thr32)) cluster_suspects(sc, node_off, __builtin_bit_cast(uint32_t, e1.w), o, d, thr, delta, sus);
+            if (!(m2 >= thr32)) cluster_suspects(sc, node_off, __builtin_bit_cast(uint32_t, e2.w), o, d, thr, delta, sus);
+            if (!(m3 >= thr32)) cluster_suspects(sc, node_off, __builtin_bit_cast(uint32_t, e3.w), o, d, thr, delta, sus);
         }
     }
     return !sus.overflow;
@@ -533,8 +533,7 @@ RT_DEV bool test_prim(const SceneDev& sc, uint32_t p, const GeomS& g, bool pass,
     } else if constexpr (LEVEL == 0 && INST) {  // RT_PRIM_INSTANCE: BVHNode object (optionally under a Transformed), main.rs:161-188
         RayInRegisters sub; sub.r.o = xo; sub.r.d = xd; sub.r.time = ray.time; sub.rinv = mk(1.0 / xd.x, 1.0 / xd.y, 1.0 / xd.z);
         const double before = h.best;
-        cptr<uint32_t> node_off = as_const(sc.node_off);
-        traverse<1, COUNT, INST, RayInRegisters, HIT>(sc, node_off[(uint32_t)g.d[0]], sub, h, pass, t_min, p, cnt);
+        traverse<1, COUNT, INST, RayInRegisters, HIT>(sc, (uint32_t)g.d[0], sub, h, pass, t_min, p, cnt);  // first node of the sub-array
         changed = (double)h.best != before;
     }
     return changed;
@@ -663,6 +662,12 @@ RT_DEV void tri2_exact(const SceneDev& sc, uint32_t node, uint32_t rec_off, lane
 template <int LEVEL, bool COUNT, bool INST, int MODE, class RAYSRC, class HIT>
 RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src, HIT& h, bool active, double t_min,
                           uint32_t inst_prim, LaneCount& cnt) {
+    // which stream: the production form, or the one with a record for every node (counting kernel, NaN-capable waves: the
+    // nesting argument behind the production form needs NaN-free slab values).  `first`: LEVEL 0 -- unused (the scene range
+    // starts at root_off), LEVEL 1 -- first node of the instance's sub-array.
+    const bool full = COUNT || MODE == BOX_LITERAL;
+    const uint32_t* node_off = full ? sc.node_off_full : sc.node_off;
+    first = LEVEL == 0 ? (full ? sc.root_off_full : sc.root_off) : as_const(node_off)[first];
     uint32_t wait = active ? first : 0xFFFFFFFFu;
     // strict pruning: top-level walks of NaN-free rays in scenes that have a pruned space; the walk starts in that space
     const bool prune = LEVEL == 0 && MODE == BOX_PLAIN && sc.prune_on != 0u;
@@ -675,7 +680,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
         d3 xo, xd;
         apply_xform(sc, sc.prune_xf, ray, xo, xd);
         Suspects sus;
-        const bool c = ray_certified(sc, xo, xd, sus) && active && ray.time >= sc.prune_time0 && ray.time <= sc.prune_time1;
+        const bool c = ray_certified(sc, node_off, xo, xd, sus) && active && ray.time >= sc.prune_time0 && ray.time <= sc.prune_time1;
         if (COUNT) cnt.uncertified += (active && !c) ? 1u : 0u;
 #ifdef RT_TRACE_DIAG
         cnt.diag_flags |= (active && !c) ? 2u : 0u;
@@ -686,7 +691,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
         ps.any_suspect = __builtin_amdgcn_ballot_w64(c && sus.leaf[0] != 0xFFFFFFFFu) != 0ull;
         RT_RECONVERGE();
     }
-    const uint64_t base = (uint64_t)sc.stream;
+    const uint64_t base = (uint64_t)(full ? sc.stream_full : sc.stream);
     cptr<rt_node> nodes = as_const(sc.nodes);
     cptr<rt_geom> geom = as_const(sc.geom);
     BoxFilter bf;
@@ -1297,6 +1302,8 @@ struct rt_scene {
     uint8_t* d_mat_uses_uv = nullptr;
     uint8_t* d_stream = nullptr;
     uint32_t* d_node_off = nullptr;
+    uint8_t* d_stream_full = nullptr;
+    uint32_t* d_node_off_full = nullptr;
     uint32_t* d_cert_cells = nullptr;
     CertEntry* d_cert_entries = nullptr;
     double* d_cert_normals = nullptr;
@@ -1799,9 +1806,12 @@ static bool range_ok(uint64_t off, uint64_t count, uint64_t elem, uint64_t total
 // follow, and the trace stream.  Also behind rt_stream_build_host, so the CPU-only tests can check the stream.
 struct ScenePrep {
     rt_blob_header h;
-    bool boxes_finite = true, reg_ray = false, has_instances = false;
+    bool boxes_finite = true, boxes_nested = false, reg_ray = false, has_instances = false;
     std::vector<uint8_t> uses_uv, stream;
     std::vector<uint32_t> rec_off, end_off;
+    std::vector<uint8_t> stream_prod;  // production stream (see prepare_scene): the full one minus the always-entered inner nodes
+    std::vector<uint32_t> rec_off_prod, end_off_prod;
+    uint32_t root_off_prod = 0, n_elided = 0;
     double box_abs_max = 0.0;
     uint32_t root_off = 0;
     PruneHost prune;
@@ -1885,6 +1895,19 @@ static int prepare_scene(const void* blob, uint64_t nbytes, ScenePrep& P) {
         if (lights[i].material >= h.n_materials) return fail(RT_ERR_BAD_BLOB, "light material out of range");
 
     for (uint32_t i = 0; i < h.n_prims; ++i) P.has_instances = P.has_instances || prims[i].kind == RT_PRIM_INSTANCE;
+    {   // do the boxes of the scene-level array nest?  (children of node i: i + 1, then along the skip links up to skip(i))
+        bool nested = boxes_finite;
+        for (uint32_t i = h.root_node; i < h.root_end && nested; ++i) {
+            const rt_node& a = nodes[i];
+            if (a.flags & RT_NODE_NO_BOX) { nested = false; break; }
+            if (a.prim0 != RT_NONE) continue;
+            for (uint32_t c = i + 1; c < a.skip && nested; c = nodes[c].skip) {
+                if (nodes[c].skip > a.skip) { nested = false; break; }
+                for (int k = 0; k < 3; ++k) nested = nested && a.bmin[k] <= nodes[c].bmin[k] && nodes[c].bmax[k] <= a.bmax[k];
+            }
+        }
+        P.boxes_nested = nested;
+    }
     // trace stream: pre-order fp32 filter records (see k_trace)
     if (h.n_nodes >= RT_STREAM_MAX_NODES) { return fail(RT_ERR_UNSUPPORTED, "more than 2^24 BVH nodes"); }
     auto is_tri2 = [&](const rt_node& nd) {  // one triangle, or two under the same transform: leaf with a filter block
@@ -1907,24 +1930,26 @@ static int prepare_scene(const void* blob, uint64_t nbytes, ScenePrep& P) {
             for (uint32_t k = prims[i].index; k < prims[i].sub_end; ++k) range_end[k] = prims[i].sub_end;
             ends_here[prims[i].sub_end] = 1;
         }
-    std::vector<uint32_t>& rec_off = P.rec_off; std::vector<uint32_t>& end_off = P.end_off;
-    rec_off.assign((size_t)h.n_nodes + 1, 0); end_off.assign((size_t)h.n_nodes + 1, 0);
-    uint64_t stream_bytes = 0;
-    for (uint32_t i = 0; i <= h.n_nodes; ++i) {
-        if (ends_here[i]) { end_off[i] = (uint32_t)stream_bytes; stream_bytes += RT_STREAM_REC; }  // END record of the range(s) ending here
-        rec_off[i] = (uint32_t)stream_bytes;
-        if (i < h.n_nodes) stream_bytes += is_tri2(nodes[i]) ? RT_STREAM_REC_TRI2 : is_sph2(nodes[i]) ? RT_STREAM_REC_SPH2 : nodes[i].prim0 != RT_NONE ? RT_STREAM_REC_LEAF : RT_STREAM_REC_INNER;
-        if (stream_bytes + RT_STREAM_PAD > 0xFFFFFFF0ull) { return fail(RT_ERR_UNSUPPORTED, "trace stream larger than 4 GiB"); }
-    }
-    // a link to the end of the node's own range lands on that range's END record
-    auto link_off = [&](uint32_t from, uint32_t to) { return to == range_end[from] ? end_off[to] : rec_off[to]; };
     auto f32_up = [](double v) {  // smallest float >= v (NaN / overflow: +inf, which disables the filter for that record)
         if (!(v <= 3.4e38)) return std::numeric_limits<float>::infinity();
         float f = (float)v;
         if ((double)f < v) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
         return f;
     };
-    std::vector<uint8_t>& stream = P.stream;
+    double& box_abs_max = P.box_abs_max;
+    // Lays the records out and fills them; `elide` marks inner nodes that get NO record (their children follow directly and
+    // links to them land on their first child): see the production stream below.
+    auto emit = [&](const std::vector<uint8_t>& elide, std::vector<uint8_t>& stream, std::vector<uint32_t>& rec_off, std::vector<uint32_t>& end_off) -> int {
+    rec_off.assign((size_t)h.n_nodes + 1, 0); end_off.assign((size_t)h.n_nodes + 1, 0);
+    uint64_t stream_bytes = 0;
+    for (uint32_t i = 0; i <= h.n_nodes; ++i) {
+        if (ends_here[i]) { end_off[i] = (uint32_t)stream_bytes; stream_bytes += RT_STREAM_REC; }  // END record of the range(s) ending here
+        rec_off[i] = (uint32_t)stream_bytes;
+        if (i < h.n_nodes && !elide[i]) stream_bytes += is_tri2(nodes[i]) ? RT_STREAM_REC_TRI2 : is_sph2(nodes[i]) ? RT_STREAM_REC_SPH2 : nodes[i].prim0 != RT_NONE ? RT_STREAM_REC_LEAF : RT_STREAM_REC_INNER;
+        if (stream_bytes + RT_STREAM_PAD > 0xFFFFFFF0ull) { return fail(RT_ERR_UNSUPPORTED, "trace stream larger than 4 GiB"); }
+    }
+    // a link to the end of the node's own range lands on that range's END record
+    auto link_off = [&](uint32_t from, uint32_t to) { return to == range_end[from] ? end_off[to] : rec_off[to]; };
     stream.assign((size_t)stream_bytes + RT_STREAM_PAD, 0);
     for (uint32_t e = 0; e <= h.n_nodes; ++e) {
         if (!ends_here[e]) continue;
@@ -1933,8 +1958,8 @@ static int prepare_scene(const void* blob, uint64_t nbytes, ScenePrep& P) {
         const uint32_t words[2] = {end_off[e], RT_NODE_NO_BOX | RT_STREAM_LEAF | ((RT_STREAM_REC / 16u) << 4) | (RT_STREAM_END_NODE << 8)};
         memcpy(stream.data() + end_off[e], box, 24); memcpy(stream.data() + end_off[e] + 24, words, 8);
     }
-    double& box_abs_max = P.box_abs_max;
     for (uint32_t i = 0; i < h.n_nodes; ++i) {
+        if (elide[i]) continue;
         const rt_node& nd = nodes[i];
         uint8_t* rec = stream.data() + rec_off[i];
         const bool nb = (nd.flags & RT_NODE_NO_BOX) != 0, tri2 = is_tri2(nd), sph2 = is_sph2(nd);
@@ -1982,14 +2007,37 @@ static int prepare_scene(const void* blob, uint64_t nbytes, ScenePrep& P) {
         }
         memcpy(rec + RT_STREAM_REC, blk, sizeof blk);
     }
+    return RT_OK;
+    };
+    // Full stream: every node has a record (the counting kernel and NaN-capable waves walk it).
+    std::vector<uint8_t> elide((size_t)h.n_nodes, 0);
+    { int rc = emit(elide, P.stream, P.rec_off, P.end_off); if (rc != RT_OK) return rc; }
+    P.root_off = h.root_node == h.root_end ? P.end_off[h.root_end] : P.rec_off[h.root_node];
+    // Production stream: inner nodes that can never be pruned and whose box holds everything that can be (the ancestors of a
+    // 1000-unit ground sphere) are entered by practically every ray -- they get no record.  Sound when boxes nest: a ray
+    // only ever visits MORE than the reference this way, and every leaf re-decides with the reference's test on its own box;
+    // a leaf box that passes with the current best implies that each ancestor box (which contains it) passed with its larger
+    // best, because the slab values are monotone in the plane coordinates.
+    if (P.prune.on && P.boxes_nested) {
+        double core_lo[3] = {INFINITY, INFINITY, INFINITY}, core_hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = h.root_node; i < h.root_end; ++i)
+            if (nodes[i].prim0 == RT_NONE && std::isfinite(P.prune.local_box[(size_t)i * 6]))
+                for (int k = 0; k < 3; ++k) { core_lo[k] = std::min(core_lo[k], nodes[i].bmin[k]); core_hi[k] = std::max(core_hi[k], nodes[i].bmax[k]); }
+        for (uint32_t i = h.root_node; i < h.root_end; ++i) {
+            if (nodes[i].prim0 != RT_NONE || std::isfinite(P.prune.local_box[(size_t)i * 6]) || !(nodes[i].skip > i + 1)) continue;
+            bool holds = true;
+            for (int k = 0; k < 3; ++k) holds = holds && nodes[i].bmin[k] <= core_lo[k] && core_hi[k] <= nodes[i].bmax[k];
+            if (holds) { elide[i] = 1; ++P.n_elided; }
+        }
+    }
+    { int rc = emit(elide, P.stream_prod, P.rec_off_prod, P.end_off_prod); if (rc != RT_OK) return rc; }
+    P.root_off_prod = h.root_node == h.root_end ? P.end_off_prod[h.root_end] : P.rec_off_prod[h.root_node];
     static_assert(RT_STREAM_REC + 28 * 4 == RT_STREAM_REC_TRI2, "TRI2 record layout");
     {
         uint64_t n_leaf = 0, n_tri_leaf = 0;
         for (uint32_t i = 0; i < h.n_nodes; ++i) { n_leaf += nodes[i].prim0 != RT_NONE; n_tri_leaf += is_tri2(nodes[i]); }
         P.reg_ray = 2 * n_tri_leaf < n_leaf;
     }
-    for (uint32_t& l : P.prune.plane_leaf) l = rec_off[l];
-    P.root_off = h.root_node == h.root_end ? end_off[h.root_end] : rec_off[h.root_node];
     return RT_OK;
 }
 
@@ -2008,6 +2056,21 @@ int rt_stream_build_host(const void* blob, uint64_t nbytes, void* stream_out, ui
     return RT_OK;
 }
 
+int rt_stream_build_prod_host(const void* blob, uint64_t nbytes, void* stream_out, uint64_t capacity, uint64_t* stream_bytes, uint32_t* root_off, uint32_t* node_off) {
+    if (!blob || !stream_bytes) return fail(RT_ERR_BAD_ARG, "rt_stream_build_prod_host: null argument");
+    ScenePrep P;
+    int rc = prepare_scene(blob, nbytes, P);
+    if (rc != RT_OK) return rc;
+    *stream_bytes = P.stream_prod.size();
+    if (root_off) *root_off = P.root_off_prod;
+    if (stream_out) {
+        if (capacity < P.stream_prod.size()) return fail(RT_ERR_BAD_ARG, "rt_stream_build_prod_host: buffer too small");
+        memcpy(stream_out, P.stream_prod.data(), P.stream_prod.size());
+    }
+    if (node_off) memcpy(node_off, P.rec_off_prod.data(), P.rec_off_prod.size() * sizeof(uint32_t));
+    return RT_OK;
+}
+
 int rt_prune_info_host(const void* blob, uint64_t nbytes, double* info, uint32_t n_rays, const double* rays, uint8_t* certified) {
     if (!blob || !info) return fail(RT_ERR_BAD_ARG, "rt_prune_info_host: null argument");
     ScenePrep P;
@@ -2016,7 +2079,7 @@ int rt_prune_info_host(const void* blob, uint64_t nbytes, double* info, uint32_t
     const PruneHost& R = P.prune;
     info[0] = R.on ? 1.0 : 0.0; info[1] = (double)R.xf; info[2] = (double)R.n_tris; info[3] = (double)R.n_prunable_nodes;
     info[4] = (double)(R.normals.size() / 3); info[5] = (double)R.entries.size(); info[6] = R.shape_min; info[7] = R.tau_coef;
-    info[8] = R.delta_coef; info[9] = R.radius; info[10] = R.box_abs_max; info[11] = 0.0;
+    info[8] = R.delta_coef; info[9] = R.radius; info[10] = R.box_abs_max; info[11] = (double)P.n_elided;
     if (n_rays && (!rays || !certified)) return fail(RT_ERR_BAD_ARG, "rt_prune_info_host: null ray arguments");
     // the device's certificate, restated on the host for rays (o, d) ALREADY in the pruned space (tests compare it with a brute-force scan)
     for (uint32_t i = 0; i < n_rays; ++i) {
@@ -2073,10 +2136,14 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     sc->has_instances = P.has_instances; sc->reg_ray = P.reg_ray;
     hipError_t e = hipMalloc(&sc->dblob, nbytes);
     if (e == hipSuccess) e = hipMalloc((void**)&sc->d_mat_uses_uv, uses_uv.size());
-    if (e == hipSuccess) e = hipMalloc((void**)&sc->d_stream, stream.size());
-    if (e == hipSuccess) e = hipMemcpy(sc->d_stream, stream.data(), stream.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc((void**)&sc->d_node_off, rec_off.size() * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemcpy(sc->d_node_off, rec_off.data(), rec_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&sc->d_stream, P.stream_prod.size());
+    if (e == hipSuccess) e = hipMemcpy(sc->d_stream, P.stream_prod.data(), P.stream_prod.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&sc->d_node_off, P.rec_off_prod.size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpy(sc->d_node_off, P.rec_off_prod.data(), P.rec_off_prod.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&sc->d_stream_full, stream.size());
+    if (e == hipSuccess) e = hipMemcpy(sc->d_stream_full, stream.data(), stream.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&sc->d_node_off_full, rec_off.size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpy(sc->d_node_off_full, rec_off.data(), rec_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(sc->dblob, blob, nbytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(sc->d_mat_uses_uv, uses_uv.data(), uses_uv.size(), hipMemcpyHostToDevice);
     const PruneHost& pr = P.prune;
@@ -2099,6 +2166,8 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
         if (sc->d_mat_uses_uv) (void)hipFree(sc->d_mat_uses_uv);
         if (sc->d_stream) (void)hipFree(sc->d_stream);
         if (sc->d_node_off) (void)hipFree(sc->d_node_off);
+        if (sc->d_stream_full) (void)hipFree(sc->d_stream_full);
+        if (sc->d_node_off_full) (void)hipFree(sc->d_node_off_full);
         if (sc->d_cert_cells) (void)hipFree(sc->d_cert_cells);
         if (sc->d_cert_entries) (void)hipFree(sc->d_cert_entries);
         if (sc->d_cert_normals) (void)hipFree(sc->d_cert_normals);
@@ -2116,7 +2185,8 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     v.materials = (const rt_material*)(d + h.off_materials); v.textures = (const rt_texture*)(d + h.off_textures);
     v.texels = d + h.off_texels; v.lights = (const rt_light*)(d + h.off_lights);
     v.mat_uses_uv = sc->d_mat_uses_uv;
-    v.stream = sc->d_stream; v.root_off = P.root_off;
+    v.stream = sc->d_stream; v.root_off = P.root_off_prod;
+    v.stream_full = sc->d_stream_full; v.node_off_full = sc->d_node_off_full; v.root_off_full = P.root_off;
     v.node_off = sc->d_node_off; v.box_abs_max = box_abs_max;
     v.cert_cells = sc->d_cert_cells; v.cert_entries = sc->d_cert_entries; v.cert_normals = sc->d_cert_normals;
     v.cert_planes = sc->d_cert_planes; v.cert_plane_off = sc->d_cert_plane_off; v.cert_plane_leaf = sc->d_cert_plane_leaf; v.cert_n_normals = (uint32_t)(pr.normals.size() / 3); v.prune_time0 = pr.time0; v.prune_time1 = pr.time1; v.prune_delta_coef = pr.delta_coef;
@@ -2159,6 +2229,8 @@ int rt_scene_destroy(rt_scene* sc) {
     (void)hipFree(sc->d_mat_uses_uv);
     (void)hipFree(sc->d_stream);
     (void)hipFree(sc->d_node_off);
+    (void)hipFree(sc->d_stream_full);
+    (void)hipFree(sc->d_node_off_full);
     if (sc->d_cert_cells) (void)hipFree(sc->d_cert_cells);
     if (sc->d_cert_entries) (void)hipFree(sc->d_cert_entries);
     if (sc->d_cert_normals) (void)hipFree(sc->d_cert_normals);

@@ -26,8 +26,11 @@ struct SceneDev {
     const uint8_t* texels;
     const rt_light* lights;
     const uint8_t* mat_uses_uv;
-    const uint8_t* stream;  // trace stream (rt_device.hip): fp32 filter records in pre-order
-    const uint32_t* node_off;  // [n_nodes + 1] byte offset of each node's record in `stream`
+    const uint8_t* stream;  // trace stream (rt_device.hip): fp32 filter records in pre-order; production form (always-entered inner nodes have no record)
+    const uint32_t* node_off;  // [n_nodes + 1] byte offset of each node's record in `stream` (a node without record: its first child's)
+    const uint8_t* stream_full;     // the same with a record for every node: counting kernel, NaN-capable waves
+    const uint32_t* node_off_full;
+    uint32_t root_off_full;
     double box_abs_max;        // max |coordinate| over the finite boxes (box filter error bound)
     // strict pruning (rt_device.hip, StrictFilter / ray_certified): one transform space, its direction grid and error constants
     const uint32_t* cert_cells;    // [3 K K + 1] CSR offsets into cert_entries
@@ -35,7 +38,7 @@ struct SceneDev {
     const double* cert_normals;    // 3 per distinct unit normal of the pruned space
     const double* cert_planes;       // per normal cluster: sorted plane offsets v0 . n^ of its triangles
     const uint32_t* cert_plane_off;  // [n_normals + 1] CSR offsets into cert_planes
-    const uint32_t* cert_plane_leaf; // parallel to cert_planes: stream offset of the triangle's leaf record
+    const uint32_t* cert_plane_leaf; // parallel to cert_planes: node index of the triangle's leaf
     double prune_tau_coef, prune_delta_coef, prune_radius, prune_box_abs_max;
     double prune_time0, prune_time1;  // covered moving spheres are boxed over this shutter; rays outside it are not pruned
     uint32_t prune_on, prune_xf, cert_n_normals;

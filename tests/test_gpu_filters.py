@@ -292,3 +292,44 @@ def test_strict_pruning_next_to_instances_mixed_leaves_and_rectangles(gpu_ctx):
     tris = np.array(verts).reshape(150, 3, 3)
     pr = _plane_rays(tris, rng, n); pr[:, 6] = rng.uniform(0, 1, n)
     _check(gpu_ctx, text, pr)
+
+
+def test_production_stream_without_always_entered_nodes(gpu_ctx):
+    # big far spheres next to a small triangle cloud under a transform: the spheres' ancestors hold every prunable box and
+    # have no record in the stream the pruning kernel walks.  Rays that MISS those ancestors' boxes
+    # in the reference (from outside, pointing away or grazing their faces) must still give the reference's answer.
+    rng = np.random.default_rng(61)
+    s = SceneText(bvh_seed=4)
+    m = s.lambertian_rgb(.5, .5, .5)
+    nt = 300
+    v0 = rng.uniform(-1, 1, (nt, 3))
+    tri = np.stack([v0, v0 + rng.normal(0, 0.1, (nt, 3)), v0 + rng.normal(0, 0.1, (nt, 3))], 1)
+    flat = tri.reshape(-1, 3)
+    me = s.mesh([tuple(map(float, p)) for p in flat], [(0, 0, 1)] * len(flat), [(0, 0)] * len(flat), [(3 * k, 3 * k + 1, 3 * k + 2) for k in range(nt)], m)
+    shift = np.array([0.5, 2.0, -0.25])
+    xf = s.xform(translate(*shift))
+    ids = [s.transformed(xf, s.triangle(me, k)) for k in range(nt)]
+    ids += [s.sphere((0.0, -1003.0 - 40.0 * i, 5.0 * i), 1000.0, m) for i in range(4)]
+    text = s.finish(ids, build_bvh=True)
+    hs = rt.HostScene.from_description(text)
+    info = hs.prune_info()
+    assert info["on"] == 1.0 and info["elided_nodes"] >= 1
+    nodes = hs.nodes()
+    n = 6000
+    org = rng.uniform(-6, 6, (n, 3)) + shift; tgt = rng.uniform(-1, 1, (n, 3)) + shift
+    o = _check(gpu_ctx, text, _rays_at(tgt, org))
+    assert (o[0] != rt.NONE).sum() > n // 10
+    # from far outside the root box, towards and away from it, and along its faces
+    root = nodes[hs.header().root_node]
+    lo, hi = root["bmin"], root["bmax"]
+    far = rng.uniform(-1, 1, (n, 3)); far /= np.linalg.norm(far, axis=1)[:, None]
+    far_o = (lo + hi) / 2 + far * 4000.0
+    _check(gpu_ctx, text, _rays_at(tgt, far_o), t_max=1e7)
+    _check(gpu_ctx, text, _rays_at(far_o * 2.0, far_o), t_max=1e7)
+    face = rng.uniform(lo, hi, (n, 3)); k = rng.integers(0, 3, n); side = rng.integers(0, 2, n)
+    face[np.arange(n), k] = np.where(side == 1, hi[k], lo[k])
+    _check(gpu_ctx, text, _rays_at(face, org, jitter_ulps=3, rng=rng), t_max=1e7)
+    slide = _rays_at(face, org); slide[:, :3] = face; slide[:, 3:6] = rng.normal(size=(n, 3)); slide[np.arange(n), 3 + k] *= 1e-9
+    _check(gpu_ctx, text, slide, t_max=1e7)
+    pr = _plane_rays(tri, rng, n); pr[:, :3] += shift
+    _check(gpu_ctx, text, pr)

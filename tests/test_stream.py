@@ -151,6 +151,69 @@ def test_walks_terminate_and_cover_each_range(name):
         assert _walk(stream, start, lambda n, f, k: False) == top
 
 
+def _ground_scene():
+    """Big far spheres around a small cloud of triangles in a space of their own: the spheres' ancestors hold every box
+    that can be pruned."""
+    rng = np.random.default_rng(11)
+    s = SceneText(bvh_seed=4)
+    m = s.lambertian_rgb(0.5, 0.5, 0.5)
+    nt = 300
+    v0 = rng.uniform(-1, 1, (nt, 3))
+    tri = np.stack([v0, v0 + rng.normal(0, 0.1, (nt, 3)), v0 + rng.normal(0, 0.1, (nt, 3))], 1).reshape(-1, 3)
+    me = s.mesh([tuple(map(float, p)) for p in tri], [(0, 0, 1)] * len(tri), [(0, 0)] * len(tri), [(3 * k, 3 * k + 1, 3 * k + 2) for k in range(nt)], m)
+    xf = s.xform(translate(0.5, 2.0, -0.25))
+    ids = [s.transformed(xf, s.triangle(me, k)) for k in range(nt)]
+    ids += [s.sphere((0.0, -1003.0 - 40.0 * i, 5.0 * i), 1000.0, m) for i in range(4)]
+    return rt.HostScene.from_description(s.finish(ids, build_bvh=True))
+
+
+@pytest.mark.parametrize("name", ["mesh", "ground", "random", "cornell", "simple_triangle"])
+def test_production_stream_drops_only_nodes_every_useful_ray_enters(name):
+    # The stream the pruning kernel walks (DESIGN.md section 5, "production stream"): inner nodes that can never be pruned
+    # and whose box holds every node that can be have no record.  Everything else is the full stream, re-linked.
+    hs = _ground_scene() if name == "ground" else rt.HostScene.builtin(name, bvh_seed=3, legacy_bvh=(name == "simple_triangle"))
+    h, nodes, info = hs.header(), hs.nodes(), hs.prune_info()
+    full, root_full, off_full = hs.trace_stream()
+    prod, root_prod, off_prod = hs.trace_stream(production=True)
+    rf, rp = _records(full), _records(prod)
+    real_f = {r["node"]: r for r in rf if r["node"] != END_NODE}
+    real_p = {r["node"]: r for r in rp if r["node"] != END_NODE}
+    gone = sorted(set(real_f) - set(real_p))
+    assert len(gone) == int(info["elided_nodes"]) and set(real_p) <= set(real_f)
+    if not info["on"]:
+        assert not gone and np.array_equal(full, prod)
+        return
+    if name in ("mesh", "ground"):
+        assert gone
+    rawf = full.tobytes()
+    local = lambda i: struct.unpack_from("<6f", rawf, int(off_full[i]) + 32)
+    inner = [i for i in range(h.root_node, h.root_end) if nodes[i]["prim0"] == rt.NONE]
+    prunable = [i for i in inner if np.isfinite(local(i)).all()]
+    core_lo = np.min([nodes[i]["bmin"] for i in prunable], axis=0); core_hi = np.max([nodes[i]["bmax"] for i in prunable], axis=0)
+    for i in gone:
+        assert i in inner and i not in prunable                             # an inner node of the scene level that is never pruned
+        assert (nodes[i]["bmin"] <= core_lo).all() and (core_hi <= nodes[i]["bmax"]).all()
+        assert off_prod[i] == off_prod[i + 1]                               # links to it land on its first child
+        for j in range(i + 1, int(nodes[i]["skip"])):                       # boxes nest below it (what the argument needs)
+            if not int(nodes[j]["flags"]) & NO_BOX:
+                assert (nodes[i]["bmin"] <= nodes[j]["bmin"]).all() and (nodes[j]["bmax"] <= nodes[i]["bmax"]).all()
+    # surviving records: same bytes apart from the link, same order; links follow the same node-level skip
+    rawp = prod.tobytes()
+    assert [r["node"] for r in rp if r["node"] != END_NODE] == [n for n in range(h.n_nodes) if n not in gone]
+    for n, r in real_p.items():
+        f = real_f[n]
+        assert r["off"] == off_prod[n] and r["size"] == f["size"]
+        assert rawp[r["off"]:r["off"] + 24] == rawf[f["off"]:f["off"] + 24] and rawp[r["off"] + 28:r["off"] + r["size"]] == rawf[f["off"] + 28:f["off"] + f["size"]]
+    keep = lambda seen: [n for n in seen if n not in gone]
+    assert _walk(prod, root_prod, lambda n, f, k: True) == keep(_walk(full, root_full, lambda n, f, k: True))
+    # any decision function that enters the dropped nodes gives the same visit order on both streams
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        coin = rng.random(h.n_nodes) < 0.7
+        dec = lambda n, f, k: bool(coin[n]) or n in gone
+        assert _walk(prod, root_prod, dec) == keep(_walk(full, root_full, dec))
+
+
 @pytest.mark.parametrize("name,seed", [("random", 1), ("random", 8), ("mesh", 3), ("simple_triangle", 0)])
 def test_walk_visits_what_the_reference_recursion_visits(name, seed):
     # Rays with a hit window [t0, t0 + 1e-12]: a box passes when the ray point at t0 lies in it, practically no surface
