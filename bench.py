@@ -65,7 +65,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="pagoda_1080p_brdf", choices=sorted(WORKLOADS))
-    ap.add_argument("--spp-per-step", type=int, default=32)
+    ap.add_argument("--spp-per-step", type=int, default=64)   # one rt_render call: two passes of 32 spp in flight on two streams
+    ap.add_argument("--one-lane", action="store_true")           # A/B: the same passes one after the other
     ap.add_argument("--bvh-seed", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -98,7 +99,7 @@ def main():
 
     def step(i, flags=0):
         b = first + i * spp_step
-        return gs.render(accum.data_ptr(), W, H, b, b + spp_step, depth, integrator, seed=0x5EED, flags=flags)
+        return gs.render(accum.data_ptr(), W, H, b, b + spp_step, depth, integrator, seed=0x5EED, flags=flags | (rt.RENDER_ONE_LANE if args.one_lane else 0))
 
     torch.cuda.synchronize()
     for i in range(args.warmup):
@@ -158,7 +159,7 @@ def main():
             "ms_per_step": t_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (reference pagoda OBJ asset, Lambertian 0.5 albedo; Philox-seeded camera samples)",
             "config": {"workload": args.workload, "scene": scene, "width": W, "height": H, "integrator": ["mis", "light_is", "brdf", "uniform"][integrator],
-                       "max_depth": depth, "spp_per_step": spp_step, "spp_total": spp_step * args.steps * world,
+                       "max_depth": depth, "spp_per_step": spp_step, "render_lanes": 1 if args.one_lane else 2, "spp_total": spp_step * args.steps * world,
                        "sharding": f"spp-range x{world}" if world > 1 else "none", "bvh_seed": args.bvh_seed},
             "paths_per_s": paths_all / t_max, "rays": rays_all, "paths": paths_all,
             "kernel_ms": {"trace": ms_trace, "shade": sum(s["ms_shade"] for s in stats), "other": sum(s["ms_other"] for s in stats),

@@ -161,11 +161,13 @@ typedef struct rt_render_params {
     int32_t max_depth;           /* main.rs:944 */
     int32_t integrator;          /* RT_INT_* */
     uint64_t seed;               /* Philox key; counter = (pixel, sample, level, block) */
-    uint32_t samples_per_pass;   /* 0 = library default; paths in flight = width*height*samples_per_pass */
+    uint32_t samples_per_pass;   /* 0 = library default; paths in flight = width*height*samples_per_pass per lane; a call of
+                                  * two or more passes runs two passes at a time on two streams */
     uint32_t flags;              /* RT_RENDER_* */
 } rt_render_params;
 #define RT_RENDER_COUNT_TESTS 1u /* also count box/primitive tests (slower kernel variant) */
 #define RT_RENDER_NO_SORT 2u     /* disable the material-binned queue (debug / A-B) */
+#define RT_RENDER_ONE_LANE 4u    /* run the passes of a call one after the other instead of two at a time (A-B; same frame) */
 
 typedef struct rt_stats {
     uint64_t rays;       /* Scene::hit-equivalent closest-hit queries: camera + bounce + MIS shadow rays */
@@ -175,7 +177,8 @@ typedef struct rt_stats {
     uint64_t sphere_tests;
     uint64_t launches;   /* kernel launches issued */
     double ms_total;     /* first ray-gen launch -> accumulators final (HIP events on the context stream) */
-    double ms_trace;     /* sum over trace_closest launches (HIP events) */
+    double ms_trace;     /* sum over trace_closest launches (HIP events on the launching stream; launches of the two lanes
+                          * overlap, so the sums of both lanes can exceed ms_total) */
     double ms_shade;     /* sum over shade launches */
     double ms_other;     /* raygen + unwind/accumulate + queue upkeep */
     uint64_t trace_launches;

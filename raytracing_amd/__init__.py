@@ -15,7 +15,7 @@ from ._ffi import ASSETS, RenderParams, Stats
 INT_MIS, INT_LIGHT_IS, INT_BRDF, INT_UNIFORM = 0, 1, 2, 3
 INTEGRATORS = {"mis": INT_MIS, "light_is": INT_LIGHT_IS, "brdf": INT_BRDF, "uniform": INT_UNIFORM}
 NONE = 0xFFFFFFFF
-RENDER_COUNT_TESTS, RENDER_NO_SORT = 1, 2
+RENDER_COUNT_TESTS, RENDER_NO_SORT, RENDER_ONE_LANE = 1, 2, 4
 
 
 class RtError(RuntimeError):

@@ -26,6 +26,9 @@
 #include <string>
 #include <limits>
 #include <vector>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
 
 using namespace rt;
 
@@ -1317,6 +1320,8 @@ struct rt_scene {
     bool reg_ray = false;   // most leaves are not triangles: k_trace variant with the f64 ray in registers
     bool sortable = false;  // scene has a finite box to quantise ray origins against
     Workspace ws;
+    Workspace ws2;                  // second render lane (rt_render runs two passes at a time, each on its own stream)
+    hipStream_t stream2 = nullptr;
 };
 
 static void ws_free(Workspace& ws) {
@@ -1331,8 +1336,9 @@ template <class T> static int ws_alloc(Workspace& ws, T*& out, size_t count) {
     out = (T*)p;
     return RT_OK;
 }
-static int ws_ensure(rt_scene* sc, uint32_t cap, int32_t depth) {
-    Workspace& ws = sc->ws;
+static int ws_ensure(rt_scene* sc, Workspace& ws, uint32_t cap, int32_t depth);
+static int ws_ensure(rt_scene* sc, uint32_t cap, int32_t depth) { return ws_ensure(sc, sc->ws, cap, depth); }
+static int ws_ensure(rt_scene* sc, Workspace& ws, uint32_t cap, int32_t depth) {
     if (ws.cap >= cap && ws.depth >= depth) return RT_OK;
     ws_free(ws);
     cap = (cap + 255u) & ~255u;
@@ -1388,17 +1394,16 @@ struct EventTimer {
 };
 enum { CAT_TRACE = 0, CAT_SHADE = 1, CAT_OTHER = 2, CAT_N = 3 };
 
-static void launch_trace(rt_scene* sc, bool count, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_bound, const double* rays, double t_min,
+static void launch_trace(rt_scene* sc, Workspace& lws, hipStream_t st, bool count, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_bound, const double* rays, double t_min,
                          double t_max, uint32_t* out_prim, uint32_t* out_inst, double* out_t, uint32_t lanes = 64u, uint32_t t_stride = 1u, PathHit* out_hit = nullptr) {
-    hipStream_t st = sc->ctx->stream;
     if (n_bound == 0) return;
     const dim3 grid((uint32_t)((((uint64_t)n_bound + lanes - 1u) / lanes + 3u) / 4u));  // waves of `lanes` rays, four waves per block
-#define RT_LAUNCH_TRACE_R(C, I, R) hipLaunchKernelGGL((k_trace<C, I, R>), grid, dim3(256), 0, st, sc->dev, queue, n_ptr, n_bound, rays, sc->ws.cap, t_min, t_max, out_prim, out_inst, out_t, sc->ws.stats, lanes, t_stride, out_hit)
+#define RT_LAUNCH_TRACE_R(C, I, R) hipLaunchKernelGGL((k_trace<C, I, R>), grid, dim3(256), 0, st, sc->dev, queue, n_ptr, n_bound, rays, lws.cap, t_min, t_max, out_prim, out_inst, out_t, lws.stats, lanes, t_stride, out_hit)
 #define RT_LAUNCH_TRACE(C, I) do { if (sc->reg_ray) RT_LAUNCH_TRACE_R(C, I, true); else RT_LAUNCH_TRACE_R(C, I, false); } while (0)
     const bool inst = sc->has_instances;  // scenes without BVHNode objects use the kernel variant compiled without the nested walk
 #ifdef RT_TRACE_DIAG
     unsigned long long d0[16];
-    (void)hipMemcpyAsync(d0, sc->ws.stats, sizeof d0, hipMemcpyDeviceToHost, st);
+    (void)hipMemcpyAsync(d0, lws.stats, sizeof d0, hipMemcpyDeviceToHost, st);
     (void)hipStreamSynchronize(st);
 #endif
     if (count) { if (inst) RT_LAUNCH_TRACE(true, true); else RT_LAUNCH_TRACE(true, false); }
@@ -1408,10 +1413,10 @@ static void launch_trace(rt_scene* sc, bool count, const uint32_t* queue, const 
 #ifdef RT_TRACE_DIAG
     {
         unsigned long long d[16];
-        (void)hipMemcpyAsync(d, sc->ws.stats, sizeof d, hipMemcpyDeviceToHost, st);
+        (void)hipMemcpyAsync(d, lws.stats, sizeof d, hipMemcpyDeviceToHost, st);
         (void)hipStreamSynchronize(st);
         for (int k = 0; k < 16; ++k) if (k != 10) d[k] -= d0[k];
-        (void)hipMemsetAsync(sc->ws.stats + 10, 0, sizeof(unsigned long long), st);
+        (void)hipMemsetAsync(lws.stats + 10, 0, sizeof(unsigned long long), st);
         const double w = (double)std::max(d[8], 1ull);
         fprintf(stderr, "[diag] rays %llu waves %llu  steps/wave %.0f  leaf steps/wave %.0f  lane use %.1f%%  cycles/wave %.0f  cycles/step %.0f  wait/step %.0f  max steps %llu  exact box steps/wave %.1f  exact tri steps/wave %.1f\n",
                 d[0], d[8], d[4] / w, d[5] / w, 100.0 * d[9] / (64.0 * std::max(d[4], 1ull)), d[7] / w, (double)d[7] / std::max(d[4], 1ull), (double)d[6] / std::max(d[4], 1ull), d[10], d[11] / w, d[12] / w);
@@ -1419,20 +1424,22 @@ static void launch_trace(rt_scene* sc, bool count, const uint32_t* queue, const 
 #endif
 }
 
+static void launch_trace(rt_scene* sc, bool count, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_bound, const double* rays, double t_min,
+                         double t_max, uint32_t* out_prim, uint32_t* out_inst, double* out_t) {
+    launch_trace(sc, sc->ws, sc->ctx->stream, count, queue, n_ptr, n_bound, rays, t_min, t_max, out_prim, out_inst, out_t);
+}
+
 // Runs the wavefront loop for n paths whose (pixel, sample) come either from explicit device lists
 // (ws.in_pixel / ws.in_sample) or from the frame formula; leaves per-path radiance in ws.pb.radiance.
 // stable LSD radix sort of the n live (key, path) pairs of a queue
-static int sort_queue(rt_scene* sc, uint32_t n, uint32_t* keys_in, uint32_t* queue_in, uint32_t* out_queue) {
-    Workspace& ws = sc->ws;
+static int sort_queue(Workspace& ws, hipStream_t st, uint32_t n, uint32_t* keys_in, uint32_t* queue_in, uint32_t* out_queue) {
     size_t bytes = ws.sort_tmp_bytes;
-    HIP_OK(rocprim::radix_sort_pairs(ws.sort_tmp, bytes, keys_in, ws.sorted_keys, queue_in, out_queue, (size_t)n, 0u, RT_SORT_BITS, sc->ctx->stream));
+    HIP_OK(rocprim::radix_sort_pairs(ws.sort_tmp, bytes, keys_in, ws.sorted_keys, queue_in, out_queue, (size_t)n, 0u, RT_SORT_BITS, st));
     return RT_OK;
 }
 
-static int run_paths(rt_scene* sc, uint32_t n, bool explicit_lists, uint32_t width, uint32_t height, uint32_t sample0, int32_t max_depth,
+static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bool explicit_lists, uint32_t width, uint32_t height, uint32_t sample0, int32_t max_depth,
                      int32_t integrator, uint64_t seed, bool count_tests, bool sort_rays, EventTimer& tm, uint64_t& launches) {
-    Workspace& ws = sc->ws;
-    hipStream_t st = sc->ctx->stream;
     const uint32_t npix = width * height;
     tm.begin(CAT_OTHER);
     hipLaunchKernelGGL(k_raygen, grid_for(n), dim3(256), 0, st, sc->dev.camera, width, height, n, sample0, npix,
@@ -1450,7 +1457,7 @@ static int run_paths(rt_scene* sc, uint32_t n, bool explicit_lists, uint32_t wid
         HIP_OK(hipMemsetAsync(ws.counts + nxt, 0, sizeof(uint32_t), st));
         HIP_OK(hipMemsetAsync(ws.counts + 2, 0, sizeof(uint32_t), st));
         tm.begin(CAT_TRACE);
-        launch_trace(sc, count_tests, ws.queue[cur], ws.counts + cur, live, ws.pb.rays, 0.001, 100000.0, nullptr, nullptr, nullptr, 64u, 1u, ws.pb.hit);  // integrator.rs:38
+        launch_trace(sc, ws, st, count_tests, ws.queue[cur], ws.counts + cur, live, ws.pb.rays, 0.001, 100000.0, nullptr, nullptr, nullptr, 64u, 1u, ws.pb.hit);  // integrator.rs:38
         tm.end();
         const bool mis_shadow = integrator == RT_INT_MIS && sc->dev.n_lights > 0;
         const bool last_bounce = bounce + 1 >= max_depth;
@@ -1467,15 +1474,15 @@ static int run_paths(rt_scene* sc, uint32_t n, bool explicit_lists, uint32_t wid
         const uint32_t next_live = std::min(ws.h_counts[nxt], n), shadow_live = std::min(ws.h_counts[2], n);
         if (sort_rays) {  // the sorted order lands in queue[nxt] / shadow_queue
             int rc = RT_OK;
-            if (mis_shadow && shadow_live) rc = sort_queue(sc, shadow_live, ws.raw_skeys, ws.raw_squeue, ws.shadow_queue);
-            if (rc == RT_OK && !last_bounce && next_live) rc = sort_queue(sc, next_live, ws.raw_keys, ws.raw_queue, ws.queue[nxt]);
+            if (mis_shadow && shadow_live) rc = sort_queue(ws, st, shadow_live, ws.raw_skeys, ws.raw_squeue, ws.shadow_queue);
+            if (rc == RT_OK && !last_bounce && next_live) rc = sort_queue(ws, st, next_live, ws.raw_keys, ws.raw_queue, ws.queue[nxt]);
             if (rc != RT_OK) return rc;
         }
         tm.end();
         launches += 2;
         if (mis_shadow && shadow_live) {
             tm.begin(CAT_TRACE);
-            launch_trace(sc, count_tests, ws.shadow_queue, ws.counts + 2, shadow_live, ws.pb.shadow_rays, 0.001, 10000.0, nullptr, nullptr,
+            launch_trace(sc, ws, st, count_tests, ws.shadow_queue, ws.counts + 2, shadow_live, ws.pb.shadow_rays, 0.001, 10000.0, nullptr, nullptr,
                          ws.pb.records + (size_t)bounce * ws.cap * REC_STRIDE + REC_T_SHADOW, 64u, (uint32_t)REC_STRIDE);  // integrator.rs:82
             tm.end();
             launches += 1;
@@ -2224,7 +2231,8 @@ int rt_scene_destroy(rt_scene* sc) {
     if (!sc) return RT_OK;
     (void)hipSetDevice(sc->ctx->device);
     (void)hipStreamSynchronize(sc->ctx->stream);
-    ws_free(sc->ws);
+    ws_free(sc->ws); ws_free(sc->ws2);
+    if (sc->stream2) (void)hipStreamDestroy(sc->stream2);
     (void)hipFree(sc->dblob);
     (void)hipFree(sc->d_mat_uses_uv);
     (void)hipFree(sc->d_stream);
@@ -2339,58 +2347,121 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
         HIP_OK(hipStreamSynchronize(sc->ctx->stream));
         return RT_OK;
     }
-    // paths in flight: as many as fit in a third of the free HBM (at most 96 GiB) and 128M paths.  Large passes matter:
-    // the deeper bounces carry few rays, and every traversal launch lasts at least as long as its slowest wave
+    // Two passes are in flight at a time, each on its own stream with its own path buffers (a "lane"): every traversal launch
+    // lasts as long as its slowest wave and the deep bounces carry few rays, so one pass alone leaves the machine part-idle
+    // for ~1/8 of its time; the other lane's kernels fill those gaps.  A pass is as large as fits in a quarter of the free
+    // HBM (at most 64 GiB) and 128M paths -- large passes matter for the same reason -- but not more than half the call's
+    // samples, so that both lanes have work.  The counting kernel runs on one lane (same passes, same sums).
     uint32_t spass = p->samples_per_pass;
     if (spass == 0) {
         size_t free_b = 0, total_b = 0;
         HIP_OK(hipMemGetInfo(&free_b, &total_b));
-        const uint64_t budget = std::min<uint64_t>(96ull << 30, (uint64_t)free_b / 3);
+        for (const Workspace* w : {&sc->ws, &sc->ws2})  // what the lanes already hold counts as free: it is re-used or released
+            free_b += (size_t)w->cap * ((size_t)std::max(w->depth, 1) * REC_STRIDE * 8 + 320);
+        const uint64_t budget = std::min<uint64_t>(64ull << 30, (uint64_t)free_b / 4);
         uint64_t by_paths = std::max<uint64_t>(1, (128ull << 20) / npix);
         uint64_t by_mem = std::max<uint64_t>(1, budget / ((uint64_t)npix * ((uint64_t)p->max_depth * REC_STRIDE * 8 + 320)));
         spass = (uint32_t)std::min<uint64_t>(std::min(by_paths, by_mem), 256);
+        spass = std::min(spass, (spp + 1u) / 2u);
     }
-    spass = std::min(spass, spp);
+    spass = std::max(1u, std::min(spass, spp));
     if ((uint64_t)npix * spass > 0x7FFFFF00ull) return fail(RT_ERR_BAD_ARG, "samples_per_pass * pixels too large");
-    rc = ws_ensure(sc, npix * spass, p->max_depth);
-    if (rc != RT_OK) return rc;
-    Workspace& ws = sc->ws;
-    hipStream_t st = sc->ctx->stream;
     const bool count_tests = (p->flags & RT_RENDER_COUNT_TESTS) != 0;
     const bool sort_rays = (p->flags & RT_RENDER_NO_SORT) == 0 && sc->sortable;
-    HIP_OK(hipMemsetAsync(ws.stats, 0, 16 * sizeof(unsigned long long), st));
-    EventTimer tm(st, stats != nullptr);
-    hipEvent_t e0, e1;
-    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    const uint32_t n_pass = (spp + spass - 1u) / spass;
+    const int n_lanes = (n_pass >= 2 && !count_tests && (p->flags & RT_RENDER_ONE_LANE) == 0) ? 2 : 1;
+    hipStream_t st = sc->ctx->stream;
+    if (n_lanes == 2 && !sc->stream2) HIP_OK(hipStreamCreateWithFlags(&sc->stream2, hipStreamNonBlocking));
+    rc = ws_ensure(sc, sc->ws, npix * spass, p->max_depth);
+    if (rc == RT_OK && n_lanes == 2) rc = ws_ensure(sc, sc->ws2, npix * spass, p->max_depth);
+    if (rc != RT_OK) return rc;
+
+    struct LaneRun {
+        Workspace* ws; hipStream_t st; EventTimer tm; uint64_t launches = 0; int rc = RT_OK; std::string err;
+        LaneRun(Workspace* w, hipStream_t s, bool timed) : ws(w), st(s), tm(s, timed) {}
+    };
+    LaneRun lane[2] = {LaneRun(&sc->ws, st, stats != nullptr), LaneRun(&sc->ws2, sc->stream2, stats != nullptr)};
+    // pass k adds its sums to the accumulator after pass k-1 did (fixed order: the frame does not depend on the lanes)
+    std::vector<hipEvent_t> added(n_pass, nullptr);
+    for (auto& e : added) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    std::mutex mu; std::condition_variable cv; uint32_t n_recorded = 0; bool broken = false;
+    hipEvent_t e0, e1, e_lane2;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1)); HIP_OK(hipEventCreateWithFlags(&e_lane2, hipEventDisableTiming));
     HIP_OK(hipEventRecord(e0, st));
-    uint64_t launches = 0;
-    for (uint32_t s0 = p->spp_begin; s0 < p->spp_end; s0 += spass) {
-        const uint32_t ns = std::min(spass, p->spp_end - s0);
-        const uint32_t n = npix * ns;
-        rc = run_paths(sc, n, false, p->width, p->height, s0, p->max_depth, p->integrator, p->seed, count_tests, sort_rays, tm, launches);
-        if (rc != RT_OK) return rc;
-        tm.begin(CAT_OTHER);
-        hipLaunchKernelGGL(k_accumulate, grid_for(npix), dim3(256), 0, st, ws.pb.radiance, ws.pb.info, ws.cap, npix, ns, accum_dev);
-        tm.end();
-        launches += 1;
+    if (n_lanes == 2) HIP_OK(hipStreamWaitEvent(sc->stream2, e0, 0));   // work queued on the caller's stream before this call comes first
+    auto run_lane = [&](int li) -> int {
+        LaneRun& L = lane[li];
+        Workspace& ws = *L.ws;
+        HIP_OK(hipSetDevice(sc->ctx->device));
+        HIP_OK(hipMemsetAsync(ws.stats, 0, 16 * sizeof(unsigned long long), L.st));
+        for (uint32_t k = (uint32_t)li; k < n_pass; k += (uint32_t)n_lanes) {
+            const uint32_t s0 = p->spp_begin + k * spass;
+            const uint32_t ns = std::min(spass, p->spp_end - s0);
+            int r = run_paths(sc, ws, L.st, npix * ns, false, p->width, p->height, s0, p->max_depth, p->integrator, p->seed, count_tests, sort_rays, L.tm, L.launches);
+            if (r != RT_OK) return r;
+            if (k > 0) {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return n_recorded >= k || broken; });
+                if (broken) return fail(RT_ERR_HIP, "the other render lane failed");
+                lk.unlock();
+                HIP_OK(hipStreamWaitEvent(L.st, added[k - 1], 0));
+            }
+            L.tm.begin(CAT_OTHER);
+            hipLaunchKernelGGL(k_accumulate, grid_for(npix), dim3(256), 0, L.st, ws.pb.radiance, ws.pb.info, ws.cap, npix, ns, accum_dev);
+            L.tm.end();
+            L.launches += 1;
+            HIP_OK(hipEventRecord(added[k], L.st));
+            { std::lock_guard<std::mutex> lk(mu); n_recorded = k + 1; }
+            cv.notify_all();
+        }
+        return RT_OK;
+    };
+    auto guarded = [&](int li) {
+        lane[li].rc = run_lane(li);
+        if (lane[li].rc != RT_OK) {
+            lane[li].err = g_err;
+            { std::lock_guard<std::mutex> lk(mu); broken = true; }
+            cv.notify_all();
+        }
+    };
+    if (n_lanes == 2) {
+        std::thread t2(guarded, 1);
+        guarded(0);
+        t2.join();
+    } else guarded(0);
+    unsigned long long st4[16] = {}, st4b[16] = {};
+    hipError_t he = hipSuccess;
+    if (n_lanes == 2) {
+        he = hipEventRecord(e_lane2, sc->stream2);
+        if (he == hipSuccess) he = hipStreamWaitEvent(st, e_lane2, 0);
+        if (he == hipSuccess) he = hipMemcpyAsync(st4b, sc->ws2.stats, sizeof st4b, hipMemcpyDeviceToHost, sc->stream2);
     }
-    HIP_OK(hipEventRecord(e1, st));
-    unsigned long long st4[16];
-    HIP_OK(hipMemcpyAsync(st4, ws.stats, sizeof st4, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipStreamSynchronize(st));
-    HIP_OK(hipGetLastError());
-    if (stats) {
+    if (he == hipSuccess) he = hipEventRecord(e1, st);
+    if (he == hipSuccess) he = hipMemcpyAsync(st4, sc->ws.stats, sizeof st4, hipMemcpyDeviceToHost, st);
+    if (n_lanes == 2) (void)hipStreamSynchronize(sc->stream2);
+    hipError_t hs = hipStreamSynchronize(st);
+    if (he == hipSuccess) he = hs;
+    if (he == hipSuccess) he = hipGetLastError();
+    for (int li = 0; li < n_lanes && rc == RT_OK; ++li)
+        if (lane[li].rc != RT_OK) { rc = lane[li].rc; g_err = lane[li].err; }
+    if (rc == RT_OK && he != hipSuccess) rc = fail(RT_ERR_HIP, std::string("rt_render: ") + hipGetErrorString(he));
+    if (stats && rc == RT_OK) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, e0, e1);
         double by_cat[CAT_N] = {0, 0, 0}; uint64_t n_by_cat[CAT_N] = {0, 0, 0};
-        tm.collect(by_cat, CAT_N, n_by_cat);
+        for (int li = 0; li < n_lanes; ++li) lane[li].tm.collect(by_cat, CAT_N, n_by_cat);
+        for (int k = 0; k < 16; ++k) st4[k] += st4b[k];
         stats->rays = st4[0]; stats->box_tests = st4[1]; stats->tri_tests = st4[2]; stats->sphere_tests = st4[3];
-        stats->paths = (uint64_t)npix * spp; stats->launches = launches;
+        stats->paths = (uint64_t)npix * spp; stats->launches = lane[0].launches + lane[1].launches;
         stats->ms_total = ms; stats->ms_trace = by_cat[CAT_TRACE]; stats->ms_shade = by_cat[CAT_SHADE]; stats->ms_other = by_cat[CAT_OTHER];
         stats->trace_launches = n_by_cat[CAT_TRACE]; stats->filter_violations = st4[13]; stats->trace_wave_steps = st4[15];
+    } else {
+        double by_cat[CAT_N] = {0, 0, 0}; uint64_t n_by_cat[CAT_N] = {0, 0, 0};
+        for (int li = 0; li < n_lanes; ++li) lane[li].tm.collect(by_cat, CAT_N, n_by_cat);   // releases the events
     }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    return RT_OK;
+    for (auto& e : added) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e_lane2);
+    return rc;
 }
 
 int rt_render_host(rt_scene* sc, const rt_render_params* p, float* accum_host, rt_stats* stats) {
@@ -2457,7 +2528,7 @@ int rt_sample_radiance(rt_scene* sc, uint32_t width, uint32_t height, uint32_t n
     HIP_OK(hipMemcpyAsync(ws.in_sample, sample_index, n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     EventTimer tm(st, false);
     uint64_t launches = 0;
-    rc = run_paths(sc, n, true, width, height, 0, max_depth, integrator, seed, false, sc->sortable, tm, launches);
+    rc = run_paths(sc, sc->ws, sc->ctx->stream, n, true, width, height, 0, max_depth, integrator, seed, false, sc->sortable, tm, launches);
     if (rc != RT_OK) return rc;
     std::vector<double> rad(3 * (size_t)ws.cap);
     HIP_OK(hipMemcpyAsync(rad.data(), ws.pb.radiance, rad.size() * sizeof(double), hipMemcpyDeviceToHost, st));

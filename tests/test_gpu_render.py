@@ -105,6 +105,23 @@ def test_spp_ranges_compose(gpu_ctx):
     gs.close()
 
 
+@pytest.mark.parametrize("name,integ", [("random", rt.INT_MIS), ("mesh", rt.INT_BRDF), ("cornell", rt.INT_MIS)])
+def test_two_render_lanes_give_the_frame_of_one(gpu_ctx, name, integ):
+    # rt_render keeps two passes in flight on two streams; each pass still adds its sums to the accumulator after the pass
+    # before it, so the frame is bit-identical to running the same passes one after the other (RT_RENDER_ONE_LANE)
+    hs, _ = _pair(name)
+    gs = gpu_ctx.upload(hs)
+    w, h = 96, 54
+    for spp, per_pass in ((7, 2), (5, 1), (6, 0), (9, 0)):
+        a, sa = gs.render_host(w, h, 1, 1 + spp, 5, integ, seed=77, samples_per_pass=per_pass)
+        b, sb = gs.render_host(w, h, 1, 1 + spp, 5, integ, seed=77, samples_per_pass=per_pass, flags=rt.RENDER_ONE_LANE)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert sa.rays == sb.rays and sa.paths == sb.paths == w * h * spp and sa.trace_launches == sb.trace_launches
+        a2, _ = gs.render_host(w, h, 1, 1 + spp, 5, integ, seed=77, samples_per_pass=per_pass)
+        assert np.array_equal(a.view(np.uint32), a2.view(np.uint32))       # and repeatable
+    gs.close()
+
+
 def test_converged_images_independent_seeds(gpu_ctx):
     # north-star "converged images": GPU (seed A) vs oracle (seed B) are independent estimates of the same
     # image; per-pixel relative RMSE over the frame must be at the Monte Carlo noise level.
