@@ -2349,8 +2349,8 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
     }
     // Two passes are in flight at a time, each on its own stream with its own path buffers (a "lane"): every traversal launch
     // lasts as long as its slowest wave and the deep bounces carry few rays, so one pass alone leaves the machine part-idle
-    // for ~1/8 of its time; the other lane's kernels fill those gaps.  A pass is as large as fits in a quarter of the free
-    // HBM (at most 64 GiB) and 128M paths -- large passes matter for the same reason -- but not more than half the call's
+    // for ~1/8 of its time; the other lane's kernels fill those gaps.  A pass is as large as fits in a third of the free
+    // HBM (at most 96 GiB) and 128M paths -- large passes matter for the same reason -- but not more than half the call's
     // samples, so that both lanes have work.  The counting kernel runs on one lane (same passes, same sums).
     uint32_t spass = p->samples_per_pass;
     if (spass == 0) {
@@ -2358,7 +2358,7 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
         HIP_OK(hipMemGetInfo(&free_b, &total_b));
         for (const Workspace* w : {&sc->ws, &sc->ws2})  // what the lanes already hold counts as free: it is re-used or released
             free_b += (size_t)w->cap * ((size_t)std::max(w->depth, 1) * REC_STRIDE * 8 + 320);
-        const uint64_t budget = std::min<uint64_t>(64ull << 30, (uint64_t)free_b / 4);
+        const uint64_t budget = std::min<uint64_t>(96ull << 30, (uint64_t)free_b / 3);
         uint64_t by_paths = std::max<uint64_t>(1, (128ull << 20) / npix);
         uint64_t by_mem = std::max<uint64_t>(1, budget / ((uint64_t)npix * ((uint64_t)p->max_depth * REC_STRIDE * 8 + 320)));
         spass = (uint32_t)std::min<uint64_t>(std::min(by_paths, by_mem), 256);
