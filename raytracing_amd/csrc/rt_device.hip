@@ -931,9 +931,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : 
     if (valid) {
         const uint32_t hp = h.prim;
         const double ht = hp != RT_NONE ? (double)h.best : __builtin_nan("");
-        if (out_hit) {  // the render loop: one 16-byte block per path
+        if (out_hit) {  // the render loop: one 16-byte block per QUEUE SLOT (k_shade walks the same queue: both sides coalesced)
             PathHit ph; ph.t = ht; ph.prim = hp; ph.inst = (uint32_t)h.inst;
-            out_hit[path] = ph;
+            out_hit[slot] = ph;
         } else {
             if (out_prim) out_prim[path] = hp;
             if (out_inst) out_inst[path] = (uint32_t)h.inst;
@@ -1003,7 +1003,7 @@ struct PathBuffers {
     double* rays;        // [7][cap]
     double* shadow_rays; // [7][cap]
     uint32_t* hit_prim; uint32_t* hit_inst; double* hit_t;  // rt_trace_closest only
-    PathHit* hit;        // [cap] closest hit of the current ray
+    PathHit* hit;        // [cap] closest hit of the current ray, by slot of the current queue
     PathInfo* info;      // [cap] pixel, sample, records written
     double* terminal;    // [3][cap] radiance returned by the last ray_colour level
     double* records;     // [depth][cap][REC_STRIDE]
@@ -1089,7 +1089,7 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, PathBuffers pb, cons
         const double4* r4 = (const double4*)(pb.rays + (size_t)path * RT_RAY_STRIDE);
         const double4 ra = r4[0], rb = r4[1];
         ray.o = mk(ra.x, ra.y, ra.z); ray.d = mk(ra.w, rb.x, rb.y); ray.time = rb.z;
-        const PathHit ph = pb.hit[path];
+        const PathHit ph = pb.hit[gid];   // written by k_trace per slot of this queue
         const uint32_t prim = ph.prim;
         d3 terminal = mk(0.0, 0.0, 0.0);
         bool done = false;
