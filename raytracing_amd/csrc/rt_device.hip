@@ -385,7 +385,9 @@ RT_DEV lanemask strict_filter(const StrictFilter& f, const Window& w) {
 }
 // Is the direction (in the pruned space) at least 2^-24 |d|_inf away from perpendicular to every triangle normal of that
 // space?  Cell of the folded cube map, then an exact f64 check of the normals listed for it (host side: cert_raster).
-#define RT_CERT_K 512u
+#ifndef RT_CERT_K
+#define RT_CERT_K 1024u
+#endif
 #define RT_CERT_EPS 0x1p-24
 struct CertEntry { float nx, ny, nz; uint32_t cluster; };  // a listed normal (fp32 copy for the first look) and its cluster
 // A ray that is nearly parallel to a triangle's plane AND starts within delta of that plane is "suspect" for the
