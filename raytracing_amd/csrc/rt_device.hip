@@ -2371,12 +2371,15 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
     const bool count_tests = (p->flags & RT_RENDER_COUNT_TESTS) != 0;
     const bool sort_rays = (p->flags & RT_RENDER_NO_SORT) == 0 && sc->sortable;
     const uint32_t n_pass = (spp + spass - 1u) / spass;
-    const int n_lanes = (n_pass >= 2 && !count_tests && (p->flags & RT_RENDER_ONE_LANE) == 0) ? 2 : 1;
+    int n_lanes = (n_pass >= 2 && !count_tests && (p->flags & RT_RENDER_ONE_LANE) == 0) ? 2 : 1;
     hipStream_t st = sc->ctx->stream;
     if (n_lanes == 2 && !sc->stream2) HIP_OK(hipStreamCreateWithFlags(&sc->stream2, hipStreamNonBlocking));
     rc = ws_ensure(sc, sc->ws, npix * spass, p->max_depth);
-    if (rc == RT_OK && n_lanes == 2) rc = ws_ensure(sc, sc->ws2, npix * spass, p->max_depth);
     if (rc != RT_OK) return rc;
+    if (n_lanes == 2 && ws_ensure(sc, sc->ws2, npix * spass, p->max_depth) != RT_OK) {  // no room for a second set of path buffers:
+        (void)hipGetLastError();                                                         // same passes, one after the other
+        n_lanes = 1;
+    }
 
     struct LaneRun {
         Workspace* ws; hipStream_t st; EventTimer tm; uint64_t launches = 0; int rc = RT_OK; std::string err;
