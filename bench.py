@@ -149,7 +149,7 @@ def main():
         if os.path.exists(pmc_path):
             try:
                 pm = json.load(open(pmc_path))
-                if pm.get("workload") == args.workload:
+                if pm.get("workload") == args.workload and pm.get("spp_per_step") == (spp_step + 1) // 2:   # counters of a pass of this size
                     traffic = pm.get("hbm_bytes_per_launch")
                     pmc = {k: pm[k] for k in ("valu_issue_utilisation", "scalar_issue_utilisation", "valu_insts_per_ray", "spp_per_step") if k in pm}
             except Exception:
