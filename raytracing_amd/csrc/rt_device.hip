@@ -2430,9 +2430,10 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
         }
     };
     if (n_lanes == 2) {
-        std::thread t2(guarded, 1);
+        std::thread t2;
+        try { t2 = std::thread(guarded, 1); } catch (...) { n_lanes = 1; }  // no second host thread: same passes on one lane (nothing has been launched yet)
         guarded(0);
-        t2.join();
+        if (t2.joinable()) t2.join();
     } else guarded(0);
     unsigned long long st4[16] = {}, st4b[16] = {};
     hipError_t he = hipSuccess;
