@@ -1324,6 +1324,7 @@ struct rt_scene {
     Workspace ws;
     Workspace ws2;                  // second render lane (rt_render runs two passes at a time, each on its own stream)
     hipStream_t stream2 = nullptr;
+    uint64_t ws2_failed_cap = ~0ull;  // smallest second-lane size (paths) that could not be allocated
 };
 
 static void ws_free(Workspace& ws) {
@@ -2363,6 +2364,10 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
         const uint64_t budget = std::min<uint64_t>(96ull << 30, (uint64_t)free_b / 3);
         uint64_t by_paths = std::max<uint64_t>(1, (128ull << 20) / npix);
         uint64_t by_mem = std::max<uint64_t>(1, budget / ((uint64_t)npix * ((uint64_t)p->max_depth * REC_STRIDE * 8 + 320)));
+        // path buffers of a previous call that are at least half the ideal size are kept as they are: the estimate moves by a
+        // sample from call to call, and re-allocating ~100 GB per call costs more than any pass size gains
+        const uint64_t have = (sc->ws.depth >= p->max_depth) ? sc->ws.cap / npix : 0;
+        if (have >= 1 && have * 2 >= std::min(by_mem, by_paths)) by_mem = by_paths = have;
         spass = (uint32_t)std::min<uint64_t>(std::min(by_paths, by_mem), 256);
         spass = std::min(spass, (spp + 1u) / 2u);
     }
@@ -2376,8 +2381,10 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
     if (n_lanes == 2 && !sc->stream2) HIP_OK(hipStreamCreateWithFlags(&sc->stream2, hipStreamNonBlocking));
     rc = ws_ensure(sc, sc->ws, npix * spass, p->max_depth);
     if (rc != RT_OK) return rc;
+    if (n_lanes == 2 && (uint64_t)npix * spass >= sc->ws2_failed_cap) n_lanes = 1;      // did not fit before
     if (n_lanes == 2 && ws_ensure(sc, sc->ws2, npix * spass, p->max_depth) != RT_OK) {  // no room for a second set of path buffers:
         (void)hipGetLastError();                                                         // same passes, one after the other
+        sc->ws2_failed_cap = (uint64_t)npix * spass;
         n_lanes = 1;
     }
 
