@@ -34,6 +34,10 @@ uint32_t rth_scene_object_count(rth_scene* s);
 
 /* exporters/ppm.rs:6-38: rgb = width*height*3 doubles (row 0 = bottom), already resolved. */
 int rth_write_ppm(const char* path, const double* rgb, uint32_t width, uint32_t height);
+/* No counterpart in the reference (output for diffing): the same frame as little-endian PFM (linear
+ * float32, rows bottom-up) and as 8-bit RGB PNG holding exactly the values rth_write_ppm prints. */
+int rth_write_pfm(const char* path, const double* rgb, uint32_t width, uint32_t height);
+int rth_write_png(const char* path, const double* rgb, uint32_t width, uint32_t height);
 /* image.rs:61-70 / 19-26 (tile helpers of the framebuffer API) */
 void rth_image_get_tile(uint32_t img_w, uint32_t img_h, uint32_t ox, uint32_t oy, uint32_t tw, uint32_t th, uint32_t* out4);
 void rth_tile_get_xy(uint32_t ox, uint32_t oy, uint32_t w, uint32_t h, uint32_t index, uint32_t* xy);

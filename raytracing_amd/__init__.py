@@ -220,3 +220,19 @@ def write_ppm(path, rgb):
     h, w = rgb.shape[:2]
     if _ffi.host().rth_write_ppm(path.encode(), rgb.ctypes.data, w, h) != 0:
         raise _host_err()
+
+
+def write_pfm(path, rgb):
+    """Linear float32 dump of a resolved frame (rows bottom-up, little endian): for diffing; no counterpart in the reference."""
+    rgb = np.ascontiguousarray(rgb, np.float64)
+    h, w = rgb.shape[:2]
+    if _ffi.host().rth_write_pfm(path.encode(), rgb.ctypes.data, w, h) != 0:
+        raise _host_err()
+
+
+def write_png(path, rgb):
+    """8-bit RGB PNG holding exactly the values write_ppm prints (sqrt gamma, clamp .999, *256 truncation)."""
+    rgb = np.ascontiguousarray(rgb, np.float64)
+    h, w = rgb.shape[:2]
+    if _ffi.host().rth_write_png(path.encode(), rgb.ctypes.data, w, h) != 0:
+        raise _host_err()

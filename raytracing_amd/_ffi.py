@@ -78,6 +78,8 @@ def host():
         L.rth_scene_object_count.restype = u32
         L.rth_scene_object_count.argtypes = [C.c_void_p]
         L.rth_write_ppm.argtypes = [C.c_char_p, C.c_void_p, u32, u32]
+        L.rth_write_pfm.argtypes = [C.c_char_p, C.c_void_p, u32, u32]
+        L.rth_write_png.argtypes = [C.c_char_p, C.c_void_p, u32, u32]
         L.rth_image_get_tile.argtypes = [u32] * 6 + [P(u32)]
         L.rth_tile_get_xy.argtypes = [u32] * 5 + [P(u32)]
         L.rth_image_merge_tile.argtypes = [C.c_void_p, u32, u32, u32, u32, u32, u32, C.c_void_p]
@@ -124,6 +126,6 @@ ABI_SYMBOLS = ["rt_device_count", "rt_context_create", "rt_context_destroy", "rt
                "rt_accum_zero", "rt_render_host", "rt_resolve", "rt_resolve_host", "rt_sample_radiance",
                "rt_ieee_div_sqrt", "rt_last_error"]
 HOST_SYMBOLS = ["rth_set_bvh_axis_seed", "rth_scene_builtin", "rth_scene_from_description", "rth_scene_free",
-                "rth_scene_describe", "rth_scene_flatten", "rth_scene_object_count", "rth_write_ppm",
+                "rth_scene_describe", "rth_scene_flatten", "rth_scene_object_count", "rth_write_ppm", "rth_write_pfm", "rth_write_png",
                 "rth_image_get_tile", "rth_tile_get_xy", "rth_image_merge_tile", "rth_mat4_inverse",
                 "rth_sphere_transform", "rth_pcg64_stream", "rth_last_error"]

@@ -166,6 +166,70 @@ void write_image(const Image& img, const std::string& location) {
     fclose(f);
 }
 
+// The two writers below have no counterpart in the reference ("PNG/PFM output for diffing"): same frame, same
+// orientation (rows bottom-up in memory), PFM keeps the linear doubles as float32, PNG holds exactly the bytes write_image prints.
+void write_pfm(const Image& img, const std::string& location) {
+    if ((size_t)img.size.first * img.size.second != img.data.size()) throw std::runtime_error("write_pfm: size mismatch");
+    FILE* f = fopen(location.c_str(), "wb");
+    if (!f) throw std::runtime_error("write_pfm: cannot create " + location);
+    fprintf(f, "PF\n%u %u\n-1.0\n", img.size.first, img.size.second);   // negative scale = little endian; PFM rows run bottom to top, like Image
+    std::vector<float> row((size_t)img.size.first * 3);
+    for (uint32_t y = 0; y < img.size.second; ++y) {
+        for (uint32_t x = 0; x < img.size.first; ++x) { const DVec3& p = *img.get(x, y); row[3 * x] = (float)p.x; row[3 * x + 1] = (float)p.y; row[3 * x + 2] = (float)p.z; }
+        if (fwrite(row.data(), sizeof(float), row.size(), f) != row.size()) { fclose(f); throw std::runtime_error("write_pfm: short write"); }
+    }
+    fclose(f);
+}
+
+void write_png(const Image& img, const std::string& location) {
+    if ((size_t)img.size.first * img.size.second != img.data.size()) throw std::runtime_error("write_png: size mismatch");
+    const uint32_t w = img.size.first, h = img.size.second;
+    auto q = [](double c) -> uint8_t {   // the quantisation of write_image (ppm.rs:20-33)
+        double p = std::pow(c, 0.5);
+        double cl = p < 0.0 ? 0.0 : (p > 0.999 ? 0.999 : p);
+        double s = cl * 256.0;
+        return s != s ? (uint8_t)0 : (uint8_t)(unsigned)s;
+    };
+    std::vector<uint8_t> raw;  // scanlines top-down, filter byte 0 each
+    raw.reserve((size_t)h * (1 + 3 * (size_t)w));
+    for (uint32_t y = h; y-- > 0;) {
+        raw.push_back(0);
+        for (uint32_t x = 0; x < w; ++x) { const DVec3& p = *img.get(x, y); raw.push_back(q(p.x)); raw.push_back(q(p.y)); raw.push_back(q(p.z)); }
+    }
+    static uint32_t table[256];
+    if (!table[1]) for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1; table[i] = c; }
+    auto be32 = [](std::vector<uint8_t>& v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); };
+    std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    auto chunk = [&](const char* type, const std::vector<uint8_t>& data) {
+        be32(out, (uint32_t)data.size());
+        const size_t start = out.size();
+        out.insert(out.end(), type, type + 4); out.insert(out.end(), data.begin(), data.end());
+        uint32_t c = 0xFFFFFFFFu;
+        for (size_t i = start; i < out.size(); ++i) c = table[(c ^ out[i]) & 0xFFu] ^ (c >> 8);
+        be32(out, c ^ 0xFFFFFFFFu);
+    };
+    std::vector<uint8_t> ihdr; be32(ihdr, w); be32(ihdr, h); ihdr.insert(ihdr.end(), {8, 2, 0, 0, 0});   // 8-bit RGB
+    chunk("IHDR", ihdr);
+    std::vector<uint8_t> z = {0x78, 0x01};   // zlib stream of stored (uncompressed) deflate blocks
+    uint32_t a = 1, b = 0;
+    for (size_t off = 0; off < raw.size() || off == 0; off += 65535) {
+        const size_t n = std::min<size_t>(65535, raw.size() - off);
+        z.push_back(off + n >= raw.size() ? 1 : 0);
+        z.push_back(n & 0xFF); z.push_back(n >> 8); z.push_back(~n & 0xFF); z.push_back((~n >> 8) & 0xFF);
+        z.insert(z.end(), raw.begin() + off, raw.begin() + off + n);
+        if (raw.empty()) break;
+    }
+    for (uint8_t v : raw) { a = (a + v) % 65521u; b = (b + a) % 65521u; }
+    be32(z, (b << 16) | a);
+    chunk("IDAT", z);
+    chunk("IEND", {});
+    FILE* f = fopen(location.c_str(), "wb");
+    if (!f) throw std::runtime_error("write_png: cannot create " + location);
+    const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+    fclose(f);
+    if (!ok) throw std::runtime_error("write_png: short write");
+}
+
 DVec3 aces_tonemapping(DVec3 pixel) {
     const double a = 2.51, b = 0.03, c = 2.43, d = 0.59, e = 0.14;
     auto ch = [&](double x) { double v = (x * (a * x + b)) / (x * (c * x + d) + e); return std::fmin(std::fmax(v, 0.0), 1.0); };

@@ -18,7 +18,10 @@ struct Assets {
 
 std::optional<Image> load_texture(const std::string& filename);                                             // main.rs:891-910 (PPM P6 input)
 std::optional<std::vector<std::vector<Triangle>>> load_obj(const std::string& file_name, Arc<Material> material);  // importers/obj.rs:6-58
-void write_image(const Image& img, const std::string& location);                                            // exporters/ppm.rs:6-38
+void write_image(const Image& img, const std::string& location);
+void write_pfm(const Image& img, const std::string& location);   // linear float32 dump for diffing (no counterpart in the reference)
+void write_png(const Image& img, const std::string& location);   // the bytes of write_image as an 8-bit RGB PNG (no counterpart)
+//                                            // exporters/ppm.rs:6-38
 DVec3 aces_tonemapping(DVec3 pixel);                                                                        // main.rs:913-921 (host copy for tools; the render path tonemaps on the GPU)
 
 SceneDescription create_cube_scene();                              // main.rs:51-91

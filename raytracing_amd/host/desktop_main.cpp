@@ -126,7 +126,10 @@ int main(int argc, char** argv) {
         Image img = Image::new_({width, height});
         for (size_t i = 0; i < img.data.size(); ++i) img.put((uint32_t)(i % width), (uint32_t)(i / width), DVec3(px[3 * i], px[3 * i + 1], px[3 * i + 2]));
         printf("Writing PPM file %s\n", out.c_str());
-        desktop::write_image(img, out);                                          // main.rs:1027
+        auto ends_with = [&](const char* e) { const size_t n = strlen(e); return out.size() >= n && out.compare(out.size() - n, n, e) == 0; };
+        if (ends_with(".pfm")) desktop::write_pfm(img, out);
+        else if (ends_with(".png")) desktop::write_png(img, out);
+        else desktop::write_image(img, out);                                     // main.rs:1027
         rt_scene_destroy(gs); rt_context_destroy(ctx);
     } catch (const std::exception& e) { fprintf(stderr, "error: %s\n", e.what()); return 1; }
     return 0;

@@ -60,6 +60,23 @@ int rth_write_ppm(const char* path, const double* rgb, uint32_t width, uint32_t 
     return 0;
     RTH_CATCH(-1)
 }
+static Image image_of(const double* rgb, uint32_t width, uint32_t height) {
+    Image img = Image::new_({width, height});
+    for (size_t i = 0; i < (size_t)width * height; ++i) img.data[i] = DVec3(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
+    return img;
+}
+int rth_write_pfm(const char* path, const double* rgb, uint32_t width, uint32_t height) {
+    RTH_TRY
+    desktop::write_pfm(image_of(rgb, width, height), path);
+    return 0;
+    RTH_CATCH(-1)
+}
+int rth_write_png(const char* path, const double* rgb, uint32_t width, uint32_t height) {
+    RTH_TRY
+    desktop::write_png(image_of(rgb, width, height), path);
+    return 0;
+    RTH_CATCH(-1)
+}
 void rth_image_get_tile(uint32_t img_w, uint32_t img_h, uint32_t ox, uint32_t oy, uint32_t tw, uint32_t th, uint32_t* out4) {
     Image img; img.size = {img_w, img_h};
     ImageTile t = img.get_tile({ox, oy}, {tw, th});

@@ -187,6 +187,36 @@ def test_ppm_writer_matches_oracle(tmp_path):  # exporters/ppm.rs:6-38
     assert vals.max() == 255 and vals[-1, 0, 0] == 0
 
 
+def test_pfm_and_png_writers(tmp_path):
+    # SURVEY.md 8(f)-2 "PNG/PFM output for diffing": no counterpart in the reference; the PNG must hold what the PPM prints
+    import zlib, struct
+    rng = np.random.default_rng(6)
+    for shape in ((7, 5, 3), (300, 257, 3)):                 # the larger one spans several stored deflate blocks
+        img = rng.uniform(-0.1, 1.3, shape); img[0, 0, 0] = np.nan
+        h, w = shape[:2]
+        p = str(tmp_path / "o.pfm")
+        rt.write_pfm(p, img)
+        raw = open(p, "rb").read()
+        head = f"PF\n{w} {h}\n-1.0\n".encode()
+        assert raw.startswith(head) and len(raw) == len(head) + 4 * img.size
+        back = np.frombuffer(raw, "<f4", img.size, len(head)).reshape(shape)
+        assert np.array_equal(back, img.astype(np.float32), equal_nan=True)          # rows bottom-up, as the accumulator
+        p = str(tmp_path / "o.png")
+        rt.write_png(p, img)
+        raw = open(p, "rb").read()
+        assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+        off, chunks = 8, []
+        while off < len(raw):
+            n, = struct.unpack(">I", raw[off:off + 4]); typ = raw[off + 4:off + 8]; data = raw[off + 8:off + 8 + n]
+            assert struct.unpack(">I", raw[off + 8 + n:off + 12 + n])[0] == zlib.crc32(typ + data)
+            chunks.append((typ, data)); off += 12 + n
+        assert [c[0] for c in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+        assert struct.unpack(">IIBBBBB", chunks[0][1]) == (w, h, 8, 2, 0, 0, 0)
+        px = np.frombuffer(zlib.decompress(chunks[1][1]), np.uint8).reshape(h, 1 + 3 * w)
+        assert not px[:, 0].any()
+        assert np.array_equal(px[:, 1:].reshape(h, w, 3), orc.quantize_ppm(img))       # top row first, same bytes as the PPM
+
+
 def test_error_behaviour():
     with pytest.raises(rt.RtError):
         rt.HostScene.from_description("not a scene")
