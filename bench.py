@@ -134,6 +134,9 @@ def main():
         # reference-order test counts of this workload (untimed counting pass on the same samples as the first timed step)
         scratch_stats = gs.render(accum.data_ptr(), W, H, first + args.warmup * spp_step, first + args.warmup * spp_step + 1, depth, integrator,
                                   seed=0x5EED, flags=rt.RENDER_COUNT_TESTS).as_dict()
+        # the same step once more on ONE lane (untimed): k_trace's launch duration without the other lane's kernels sharing the machine
+        alone = gs.render(accum.data_ptr(), W, H, first + args.warmup * spp_step, first + (args.warmup + 1) * spp_step, depth, integrator,
+                          seed=0x5EED, flags=rt.RENDER_ONE_LANE).as_dict()
         r1 = max(scratch_stats["rays"], 1)
         n_box, n_tri, n_sph = scratch_stats["box_tests"] / r1, scratch_stats["tri_tests"] / r1, scratch_stats["sphere_tests"] / r1
         wave_steps = sum(s["trace_wave_steps"] for s in stats)
@@ -167,6 +170,8 @@ def main():
             "roofline": {"kernel": "k_trace<false>", "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_ray": bytes_per_ray, "rays_per_launch": rays_per_launch, "avg_launch_ms": avg_launch_s * 1e3,
+                         # avg_launch_ms is elapsed time under sharing when two lanes are in flight; alone = same launches, one lane, untimed extra step
+                         "avg_launch_ms_one_lane": alone["ms_trace"] / max(alone["trace_launches"], 1), "one_lane_step_ms": alone["ms_total"],
                          "tests_per_ray": {"box": n_box, "tri": n_tri, "sph": n_sph},
                          "note": "algorithmic bytes are the per-ray node/primitive fetches of the REFERENCE-ORDER traversal (SURVEY.md 8d), counted by an "
                                  "untimed pass of the counting kernel; the production kernel skips every subtree whose triangle box the ray's line provably "
