@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="pagoda_1080p_brdf", choices=sorted(WORKLOADS))
-    ap.add_argument("--spp-per-step", type=int, default=120)  # one rt_render call: two passes of 60 spp in flight on two streams
+    ap.add_argument("--spp-per-step", type=int, default=100)  # one rt_render call = the whole configs[1] job (1080p, 100 spp): two passes of 50 spp in flight on two streams
     ap.add_argument("--one-lane", action="store_true")           # A/B: the same passes one after the other
     ap.add_argument("--bvh-seed", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
