@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 W, H, SPP, DEPTH, INTEG, SEED = 24, 14, 5, 4, 0, 123
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, progressive=False):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -35,7 +35,24 @@ def _worker(rank, world, port, out_dir):
     def render_fn(accum, b, e):
         img, _ = osc.render(W, H, b, e, DEPTH, INTEG, seed=SEED)
         accum += torch.from_numpy(img.astype(np.float32))
-    acc = rtd.render_sharded(render_fn, W, H, SPP, dev)
+    if progressive:
+        # each rank renders its own sample range chunk by chunk with a checkpoint file of its own; rank 1 is interrupted after
+        # its first chunk and a NEW ProgressiveRender picks the file up; the all-reduce comes last
+        from raytracing_amd import progressive as pg
+        lo, hi = rtd.spp_range(rank, world, SPP)
+        fn = lambda a, b: osc.render(W, H, a, b, DEPTH, INTEG, seed=SEED)[0].astype(np.float32)
+        path = os.path.join(out_dir, "frame.ckpt")
+        pr = pg.ProgressiveRender(fn, blob, W, H, lo, hi, DEPTH, INTEG, SEED, chunk=1, path=path, rank=rank, world=world)
+        pr.run(stop=lambda: rank == 1)
+        if rank == 1:
+            assert pr.spp_done == 1 and not pr.complete
+            pr = pg.ProgressiveRender.resume(fn, blob, path, chunk=1, rank=rank, world=world, expect=dict(seed=SEED, max_depth=DEPTH))
+            pr.run()
+        assert pr.complete and pr.spp_done == hi - lo
+        acc = torch.from_numpy(pr.accum.copy())
+        rtd.allreduce_accum(acc)
+    else:
+        acc = rtd.render_sharded(render_fn, W, H, SPP, dev)
     np.save(os.path.join(out_dir, f"acc{rank}.npy"), acc.numpy())
     np.save(os.path.join(out_dir, f"range{rank}.npy"), np.array(rtd.spp_range(rank, world, SPP)))
     with open(os.path.join(out_dir, f"blob{rank}.bin"), "wb") as f:
@@ -66,3 +83,21 @@ def test_two_rank_gloo_render_equals_single(tmp_path):
     osc = orc.OracleScene(rt.HostScene.builtin("random", bvh_seed=1).describe())
     full, _ = osc.render(W, H, 0, SPP, DEPTH, INTEG, seed=SEED)
     assert np.allclose(a0, full, rtol=1e-6, atol=1e-6)              # equal up to fp32 summation order
+
+
+def test_two_rank_progressive_render_with_an_interrupted_rank(tmp_path):
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), True), nprocs=2, join=True)
+    a0, a1 = np.load(tmp_path / "acc0.npy"), np.load(tmp_path / "acc1.npy")
+    assert np.array_equal(a0, a1)
+    assert sorted(f for f in os.listdir(tmp_path) if "ckpt" in f) == ["frame.ckpt.rank0", "frame.ckpt.rank1"]
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_ffi as orc
+    import raytracing_amd as rt
+    from raytracing_amd import progressive as pg
+    osc = orc.OracleScene(rt.HostScene.builtin("random", bvh_seed=1).describe())
+    full, _ = osc.render(W, H, 0, SPP, DEPTH, INTEG, seed=SEED)
+    assert np.allclose(a0, full, rtol=1e-6, atol=1e-6)
+    h0, s0 = pg.load_checkpoint(str(tmp_path / "frame.ckpt.rank0")); h1, s1 = pg.load_checkpoint(str(tmp_path / "frame.ckpt.rank1"))
+    assert (h0["spp_begin"], h0["spp_done"], h1["spp_begin"], h1["spp_done"], h1["world"]) == (0, 2, 2, 5, 2)
+    assert np.allclose(s0.astype(np.float64) + s1, full, rtol=1e-6, atol=1e-6)     # the ranks' files alone reproduce the frame
