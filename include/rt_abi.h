@@ -189,7 +189,8 @@ typedef struct rt_stats {
 /* number of visible HIP devices (>= 0) or negative error */
 int rt_device_count(void);
 /* Creates a context on `device` with its own stream.  `stream` may be a caller hipStream_t (cast
- * to void*, e.g. torch.cuda.current_stream().cuda_stream) or NULL for a library-owned stream. */
+ * to void*, e.g. torch.cuda.current_stream().cuda_stream) or NULL for a library-owned stream.
+ * Also takes the device address of this GPU's fixed scratch array (rt_trace_closest_device_noalloc). */
 int rt_context_create(int device, void* stream, rt_context** out);
 int rt_context_destroy(rt_context* ctx);
 int rt_context_synchronize(rt_context* ctx);
@@ -231,6 +232,15 @@ int rt_trace_closest(rt_scene* scene, uint32_t n, const double* rays, double t_m
  * the context stream.  This is the entry bench.py times for the traversal kernel alone. */
 int rt_trace_closest_device(rt_scene* scene, uint32_t n, const double* rays_dev, double t_min, double t_max,
                             uint32_t* prim_id_dev, double* t_dev);
+/* rt_trace_closest_device for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  NO counterpart in the reference.  Same arguments, same outputs (prim_id_dev: index into the
+ * blob's prims table or RT_NONE; t_dev: NaN on a miss), asynchronous on the context stream, but it calls no hipMalloc /
+ * hipFree: the 64-byte ray blocks the kernel reads and its counters live in a fixed array inside the library
+ * (16 MiB + 256 B per GPU, held until the process ends).  n > 262144 -> RT_ERR_BAD_ARG.  Every call on a GPU shares that
+ * GPU's array: calls that overlap on one GPU (two contexts / streams) race; calls on one context's stream are ordered. */
+#define RT_NOALLOC_MAX_RAYS_ABI 262144u
+int rt_trace_closest_device_noalloc(rt_scene* scene, uint32_t n, const double* rays_dev, double t_min, double t_max,
+                                    uint32_t* prim_id_dev, double* t_dev);
 
 /* Camera rays (main.rs:996-999 + camera.rs:83-101) of one sample index for every pixel, written
  * to host `rays` (width*height x 7 doubles, row 0 = bottom row). */

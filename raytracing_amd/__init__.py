@@ -16,6 +16,7 @@ INT_MIS, INT_LIGHT_IS, INT_BRDF, INT_UNIFORM = 0, 1, 2, 3
 INTEGRATORS = {"mis": INT_MIS, "light_is": INT_LIGHT_IS, "brdf": INT_BRDF, "uniform": INT_UNIFORM}
 NONE = 0xFFFFFFFF
 RENDER_COUNT_TESTS, RENDER_NO_SORT, RENDER_ONE_LANE = 1, 2, 4
+NOALLOC_MAX_RAYS = 262144
 
 
 class RtError(RuntimeError):
@@ -171,6 +172,10 @@ class GpuScene:
 
     def trace_closest_device(self, n, rays_ptr, t_min, t_max, prim_ptr, t_ptr):
         _hip_check(_ffi.hip().rt_trace_closest_device(self._h, n, C.c_void_p(rays_ptr), t_min, t_max, C.c_void_p(prim_ptr), C.c_void_p(t_ptr)))
+
+    def trace_closest_device_noalloc(self, n, rays_ptr, t_min, t_max, prim_ptr, t_ptr):
+        """rt_trace_closest_device without any allocation (fixed scratch inside the library, n <= NOALLOC_MAX_RAYS)."""
+        _hip_check(_ffi.hip().rt_trace_closest_device_noalloc(self._h, n, C.c_void_p(rays_ptr), t_min, t_max, C.c_void_p(prim_ptr), C.c_void_p(t_ptr)))
 
     def primary_rays(self, width, height, sample, seed):
         rays = np.empty((width * height, 7), np.float64)

@@ -1281,10 +1281,19 @@ __global__ void k_div_sqrt(uint32_t n, const double* a, const double* b, double*
 // ------------------------------------------------------------------------------------------------
 // host side of the ABI
 // ------------------------------------------------------------------------------------------------
+// Scratch of rt_trace_closest_device_noalloc (the entry point for callers that cannot allocate): the statistics
+// counters k_trace adds to, then one 64-byte ray block per ray (the layout k_trace reads).  Every GPU the library runs
+// on holds its own copy of this array until the process ends.  In host code the NAME is only a stand-in: the device
+// address is taken once per device with hipGetSymbolAddress (rt_context_create) and kept in rt_context::scratch.
+#define RT_NOALLOC_MAX_RAYS (1u << 18)
+#define RT_NOALLOC_STATS_BYTES 256u
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_STATS_BYTES + (size_t)RT_NOALLOC_MAX_RAYS * RT_RAY_STRIDE * sizeof(double)];
+
 struct rt_context {
     int device;
     hipStream_t stream;
     bool own_stream;
+    unsigned char* scratch;  // this device's copy of `scratch` (device address)
 };
 
 struct Workspace {
@@ -1397,16 +1406,16 @@ struct EventTimer {
 };
 enum { CAT_TRACE = 0, CAT_SHADE = 1, CAT_OTHER = 2, CAT_N = 3 };
 
-static void launch_trace(rt_scene* sc, Workspace& lws, hipStream_t st, bool count, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_bound, const double* rays, double t_min,
+static void launch_trace(rt_scene* sc, unsigned long long* lstats, uint32_t lcap, hipStream_t st, bool count, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_bound, const double* rays, double t_min,
                          double t_max, uint32_t* out_prim, uint32_t* out_inst, double* out_t, uint32_t lanes = 64u, uint32_t t_stride = 1u, PathHit* out_hit = nullptr) {
     if (n_bound == 0) return;
     const dim3 grid((uint32_t)((((uint64_t)n_bound + lanes - 1u) / lanes + 3u) / 4u));  // waves of `lanes` rays, four waves per block
-#define RT_LAUNCH_TRACE_R(C, I, R) hipLaunchKernelGGL((k_trace<C, I, R>), grid, dim3(256), 0, st, sc->dev, queue, n_ptr, n_bound, rays, lws.cap, t_min, t_max, out_prim, out_inst, out_t, lws.stats, lanes, t_stride, out_hit)
+#define RT_LAUNCH_TRACE_R(C, I, R) hipLaunchKernelGGL((k_trace<C, I, R>), grid, dim3(256), 0, st, sc->dev, queue, n_ptr, n_bound, rays, lcap, t_min, t_max, out_prim, out_inst, out_t, lstats, lanes, t_stride, out_hit)
 #define RT_LAUNCH_TRACE(C, I) do { if (sc->reg_ray) RT_LAUNCH_TRACE_R(C, I, true); else RT_LAUNCH_TRACE_R(C, I, false); } while (0)
     const bool inst = sc->has_instances;  // scenes without BVHNode objects use the kernel variant compiled without the nested walk
 #ifdef RT_TRACE_DIAG
     unsigned long long d0[16];
-    (void)hipMemcpyAsync(d0, lws.stats, sizeof d0, hipMemcpyDeviceToHost, st);
+    (void)hipMemcpyAsync(d0, lstats, sizeof d0, hipMemcpyDeviceToHost, st);
     (void)hipStreamSynchronize(st);
 #endif
     if (count) { if (inst) RT_LAUNCH_TRACE(true, true); else RT_LAUNCH_TRACE(true, false); }
@@ -1416,10 +1425,10 @@ static void launch_trace(rt_scene* sc, Workspace& lws, hipStream_t st, bool coun
 #ifdef RT_TRACE_DIAG
     {
         unsigned long long d[16];
-        (void)hipMemcpyAsync(d, lws.stats, sizeof d, hipMemcpyDeviceToHost, st);
+        (void)hipMemcpyAsync(d, lstats, sizeof d, hipMemcpyDeviceToHost, st);
         (void)hipStreamSynchronize(st);
         for (int k = 0; k < 16; ++k) if (k != 10) d[k] -= d0[k];
-        (void)hipMemsetAsync(lws.stats + 10, 0, sizeof(unsigned long long), st);
+        (void)hipMemsetAsync(lstats + 10, 0, sizeof(unsigned long long), st);
         const double w = (double)std::max(d[8], 1ull);
         fprintf(stderr, "[diag] rays %llu waves %llu  steps/wave %.0f  leaf steps/wave %.0f  lane use %.1f%%  cycles/wave %.0f  cycles/step %.0f  wait/step %.0f  max steps %llu  exact box steps/wave %.1f  exact tri steps/wave %.1f\n",
                 d[0], d[8], d[4] / w, d[5] / w, 100.0 * d[9] / (64.0 * std::max(d[4], 1ull)), d[7] / w, (double)d[7] / std::max(d[4], 1ull), (double)d[6] / std::max(d[4], 1ull), d[10], d[11] / w, d[12] / w);
@@ -1429,7 +1438,7 @@ static void launch_trace(rt_scene* sc, Workspace& lws, hipStream_t st, bool coun
 
 static void launch_trace(rt_scene* sc, bool count, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_bound, const double* rays, double t_min,
                          double t_max, uint32_t* out_prim, uint32_t* out_inst, double* out_t) {
-    launch_trace(sc, sc->ws, sc->ctx->stream, count, queue, n_ptr, n_bound, rays, t_min, t_max, out_prim, out_inst, out_t);
+    launch_trace(sc, sc->ws.stats, sc->ws.cap, sc->ctx->stream, count, queue, n_ptr, n_bound, rays, t_min, t_max, out_prim, out_inst, out_t);
 }
 
 // Runs the wavefront loop for n paths whose (pixel, sample) come either from explicit device lists
@@ -1460,7 +1469,7 @@ static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bo
         HIP_OK(hipMemsetAsync(ws.counts + nxt, 0, sizeof(uint32_t), st));
         HIP_OK(hipMemsetAsync(ws.counts + 2, 0, sizeof(uint32_t), st));
         tm.begin(CAT_TRACE);
-        launch_trace(sc, ws, st, count_tests, ws.queue[cur], ws.counts + cur, live, ws.pb.rays, 0.001, 100000.0, nullptr, nullptr, nullptr, 64u, 1u, ws.pb.hit);  // integrator.rs:38
+        launch_trace(sc, ws.stats, ws.cap, st, count_tests, ws.queue[cur], ws.counts + cur, live, ws.pb.rays, 0.001, 100000.0, nullptr, nullptr, nullptr, 64u, 1u, ws.pb.hit);  // integrator.rs:38
         tm.end();
         const bool mis_shadow = integrator == RT_INT_MIS && sc->dev.n_lights > 0;
         const bool last_bounce = bounce + 1 >= max_depth;
@@ -1485,7 +1494,7 @@ static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bo
         launches += 2;
         if (mis_shadow && shadow_live) {
             tm.begin(CAT_TRACE);
-            launch_trace(sc, ws, st, count_tests, ws.shadow_queue, ws.counts + 2, shadow_live, ws.pb.shadow_rays, 0.001, 10000.0, nullptr, nullptr,
+            launch_trace(sc, ws.stats, ws.cap, st, count_tests, ws.shadow_queue, ws.counts + 2, shadow_live, ws.pb.shadow_rays, 0.001, 10000.0, nullptr, nullptr,
                          ws.pb.records + (size_t)bounce * ws.cap * REC_STRIDE + REC_T_SHADOW, 64u, (uint32_t)REC_STRIDE);  // integrator.rs:82
             tm.end();
             launches += 1;
@@ -1784,6 +1793,12 @@ int rt_context_create(int device, void* stream, rt_context** out) {
     rt_context* c = new (std::nothrow) rt_context();
     if (!c) return fail(RT_ERR_OOM, "rt_context_create: host allocation failed");
     c->device = device;
+    {   // device address of this GPU's copy of the no-alloc scratch array (the device is current: hipSetDevice above)
+        void* ptr = nullptr;
+        hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) { delete c; return fail(RT_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e)); }
+        c->scratch = (unsigned char*)ptr;
+    }
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -2261,6 +2276,22 @@ int rt_trace_closest_device(rt_scene* sc, uint32_t n, const double* rays_dev, do
     hipStream_t st = sc->ctx->stream;
     hipLaunchKernelGGL(k_aos_to_soa, grid_for(n), dim3(256), 0, st, rays_dev, n, sc->ws.pb.rays, sc->ws.cap);
     launch_trace(sc, false, nullptr, nullptr, n, sc->ws.pb.rays, t_min, t_max, prim_id_dev, nullptr, t_dev);
+    HIP_OK(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_trace_closest_device_noalloc(rt_scene* sc, uint32_t n, const double* rays_dev, double t_min, double t_max, uint32_t* prim_id_dev, double* t_dev) {
+    if (!sc || (n && (!rays_dev || !prim_id_dev || !t_dev))) return fail(RT_ERR_BAD_ARG, "rt_trace_closest_device_noalloc: null argument");
+    if (n > RT_NOALLOC_MAX_RAYS) return fail(RT_ERR_BAD_ARG, "rt_trace_closest_device_noalloc: more than " + std::to_string(RT_NOALLOC_MAX_RAYS) + " rays per call (the scratch array is fixed)");
+    if (n == 0) return RT_OK;
+    HIP_OK(hipSetDevice(sc->ctx->device));
+    hipStream_t st = sc->ctx->stream;
+    unsigned char* base = sc->ctx->scratch;  // never the array's name: that is a host-side stand-in, not a device address
+    unsigned long long* stats = (unsigned long long*)base;
+    double* staged = (double*)(base + RT_NOALLOC_STATS_BYTES);
+    HIP_OK(hipMemsetAsync(stats, 0, 16 * sizeof(unsigned long long), st));  // the array keeps the last call's contents; the ray blocks are rewritten below
+    hipLaunchKernelGGL(k_aos_to_soa, grid_for(n), dim3(256), 0, st, rays_dev, n, staged, RT_NOALLOC_MAX_RAYS);
+    launch_trace(sc, stats, RT_NOALLOC_MAX_RAYS, st, false, nullptr, nullptr, n, staged, t_min, t_max, prim_id_dev, nullptr, t_dev);
     HIP_OK(hipGetLastError());
     return RT_OK;
 }
