@@ -161,12 +161,14 @@ typedef struct rt_render_params {
     int32_t max_depth;           /* main.rs:944 */
     int32_t integrator;          /* RT_INT_* */
     uint64_t seed;               /* Philox key; counter = (pixel, sample, level, block) */
-    uint32_t samples_per_pass;   /* 0 = library default; paths in flight = width*height*samples_per_pass per lane; a call of
-                                  * two or more passes runs two passes at a time on two streams */
+    uint32_t samples_per_pass;   /* 0 = library default, a pure function of (width*height, max_depth, spp_end - spp_begin): 80 GiB of path state,
+                                  * 128M paths, half the call's samples, whichever is smallest -- never of free memory or call history, because
+                                  * pass boundaries fix the order of the fp32 sums.  Paths in flight = width*height*samples_per_pass per lane; a call
+                                  * of two or more passes runs two passes at a time on two streams */
     uint32_t flags;              /* RT_RENDER_* */
 } rt_render_params;
 #define RT_RENDER_COUNT_TESTS 1u /* also count box/primitive tests (slower kernel variant) */
-#define RT_RENDER_NO_SORT 2u     /* disable the material-binned queue (debug / A-B) */
+#define RT_RENDER_NO_SORT 2u     /* do not sort the ray queues by coherence key (octant | origin cell | direction bin); debug / A-B */
 #define RT_RENDER_ONE_LANE 4u    /* run the passes of a call one after the other instead of two at a time (A-B; same frame) */
 
 typedef struct rt_stats {
@@ -184,6 +186,11 @@ typedef struct rt_stats {
     uint64_t trace_launches;
     uint64_t trace_wave_steps;  /* stream records stepped through, summed over the waves of every traversal launch (one record = one box or leaf test for up to 64 rays) */
     uint64_t filter_violations; /* only with RT_RENDER_COUNT_TESTS: fp32 filter decisions contradicted by the exact f64 test; 0 by construction */
+    double ms_trace_shadow;          /* the part of ms_trace spent in launches over MIS shadow rays (integrator.rs:82) */
+    uint64_t trace_shadow_launches;  /* the part of trace_launches that traced shadow rays */
+    uint64_t shadow_rays;            /* the part of `rays` that were shadow rays */
+    uint32_t samples_per_pass;       /* pass size the call used (a pure function of the parameters when samples_per_pass == 0) */
+    uint32_t lanes;                  /* render lanes the call used (1 or 2) */
 } rt_stats;
 
 /* number of visible HIP devices (>= 0) or negative error */
@@ -256,6 +263,16 @@ int rt_accum_zero(rt_context* ctx, float* accum_dev, uint32_t width, uint32_t he
  * device accumulator internally, renders, copies the sums to host accum (width*height*3 fp32). */
 int rt_render_host(rt_scene* scene, const rt_render_params* params, float* accum_host, rt_stats* stats);
 
+/* Test hook, no counterpart in the reference: runs the render loop for ONE sample index of every pixel (spp_end == spp_begin + 1;
+ * the kernels, queues and sorts of rt_render) up to the traversal launch of `bounce` and copies out every stride-th ray of that
+ * launch's queue (shadow = 0: the path rays; 1: the MIS shadow rays, integrator.rs:82), at most max_n.  Host outputs: rays n x 7;
+ * for path rays prim_id / inst_id / t = the closest hit exactly as the render loop's own launch recorded it (object ids as in
+ * rt_trace_closest, t = NaN on a miss); for shadow rays t = what the visibility walk reported (it stops at the first accepted hit
+ * that already decides "not visible", so only `|t - t_light| <= 1e-4` is meaningful) and t_light = light.hit(ray).t.
+ * *queue_len (may be NULL) = rays in that queue.  Parity tests hand these rays of the real frame to the oracle. */
+int rt_capture_rays(rt_scene* scene, const rt_render_params* params, uint32_t bounce, int shadow, uint32_t stride, uint32_t max_n,
+                    uint32_t* n_out, uint32_t* queue_len, double* rays, uint32_t* prim_id, uint32_t* inst_id, double* t, double* t_light);
+
 /* accum sums -> displayable pixels: /spp, optional ACES (main.rs:913-921), NaN channel -> 0
  * (image.rs:48-56).  Device in, device out (width*height*3 fp32; may alias). */
 int rt_resolve(rt_context* ctx, const float* accum_dev, uint32_t width, uint32_t height, uint32_t spp, int tonemap,
@@ -266,6 +283,23 @@ int rt_resolve_host(const float* accum_host, uint32_t width, uint32_t height, ui
  * samples (pixel_index[i], sample_index[i]).  Used by the parity tests to compare single paths. */
 int rt_sample_radiance(rt_scene* scene, uint32_t width, uint32_t height, uint32_t n, const uint32_t* pixel_index,
                        const uint32_t* sample_index, int32_t max_depth, int32_t integrator, uint64_t seed, double* out_rgb);
+
+/* PDF::value / PDF::generate (renderer/src/pdf.rs:9-15) for n independent items on the device, for parity tests of the
+ * PDF set by itself.  Item i is a list of n_comp PDFs pdfs[i*n_comp ..]: n_comp == 1 evaluates that PDF, n_comp in 2..8
+ * evaluates MixturePDF with MixtureMethod::Uniform over the list (pdf.rs:185-224: value = sum of value_k / n, generate =
+ * one uniformly chosen member's sample, normalised).  The random stream of item i is Philox (seed; i, 0, 0).
+ * Fields by kind (the reference's constructors, pdf.rs):  COSINE / UNIFORM_HEMI: a = normal;  UNIFORM_SPHERE: a = centre,
+ * s = radius;  FUZZY: a = direction as stored (already normalised, pdf.rs:87-91), s = fuzz;  DIELECTRIC: a = reflect_dir,
+ * b = refract_dir, s = reflectance, cannot_refract;  CONE: a = axis, s = cos_theta_max.  All host pointers. */
+#define RT_PDF_COSINE 0u
+#define RT_PDF_UNIFORM_HEMI 1u
+#define RT_PDF_UNIFORM_SPHERE 2u
+#define RT_PDF_FUZZY 3u
+#define RT_PDF_DIELECTRIC 4u
+#define RT_PDF_CONE 5u
+typedef struct rt_pdf_desc { uint32_t kind; uint32_t cannot_refract; double a[3], b[3], s; } rt_pdf_desc; /* 64 B */
+int rt_pdf_eval(rt_context* ctx, uint32_t n, uint32_t n_comp, const rt_pdf_desc* pdfs, const double* dirs, uint64_t seed,
+                double* value, double* generated);
 
 /* IEEE check helper: q[i] = a[i]/b[i], s[i] = sqrt(a[i]) computed on the device with the same
  * compiler flags as the kernels (host arrays). */

@@ -27,7 +27,8 @@ typedef struct rt_checkpoint_header {
     int32_t max_depth;
     int32_t integrator;      /* RT_INT_* */
     uint32_t rank, world;    /* informational: which shard of an spp-sharded render */
-    uint32_t reserved;
+    uint32_t chunk;          /* samples added per fp32 addition into the sums (0 = not recorded): a resume with another chunk size is refused,
+                              * because it would add the same samples in another grouping and the sums would differ in the last bits */
     uint64_t seed;
     uint64_t scene_id;       /* (blob length << 32) | CRC-32 (IEEE, zlib's) of the RTSB blob: resuming on another scene is refused */
 } rt_checkpoint_header;      /* 64 bytes */

@@ -187,6 +187,37 @@ void orc_mat4_inverse(const double* m, double* out) {
     const V4* c[4] = {&r.c0, &r.c1, &r.c2, &r.c3};
     for (int i = 0; i < 4; ++i) { out[4 * i] = c[i]->x; out[4 * i + 1] = c[i]->y; out[4 * i + 2] = c[i]->z; out[4 * i + 3] = c[i]->w; }
 }
+// PDF::value / PDF::generate for n items of n_comp PDFs each (n_comp > 1: MixturePdf), same argument meaning as rt_pdf_eval
+// (desc = kind u32, cannot_refract u32, a[3], b[3], s: 64 B); `skip` draws of item i's stream are discarded first (tests only).
+int orc_pdf_eval(uint32_t n, uint32_t n_comp, const void* descs, const double* dirs, uint64_t seed, uint32_t skip, double* value, double* generated) {
+    struct Desc { uint32_t kind, cannot_refract; double a[3], b[3], s; };
+    static_assert(sizeof(Desc) == 64, "rt_pdf_desc layout");
+    const Desc* d = (const Desc*)descs;
+    for (uint32_t i = 0; i < n; ++i) {
+        MixturePdf mix;
+        for (uint32_t c = 0; c < n_comp; ++c) {
+            const Desc& e = d[(size_t)i * n_comp + c];
+            Pdf p; const V3 a(e.a[0], e.a[1], e.a[2]);
+            switch (e.kind) {
+                case 0: p = Pdf::cosine(a); break;
+                case 1: p = Pdf::uniform_hemi(a); break;
+                case 2: p = Pdf::uniform_sphere(a, e.s); break;
+                case 3: p.kind = Pdf::FUZZY_DELTA; p.dir = a; p.fuzz = e.s; break;   // direction as stored
+                case 4: p.kind = Pdf::DIELECTRIC; p.reflect_dir = a; p.refract_dir = V3(e.b[0], e.b[1], e.b[2]); p.refl = e.s; p.cannot_refract = e.cannot_refract != 0; break;
+                case 5: p = Pdf::cone(a, e.s); break;
+                default: g_err = "orc_pdf_eval: unknown kind"; return -1;
+            }
+            mix.pdfs.push_back(p);
+        }
+        const V3 dir(dirs[3 * (size_t)i], dirs[3 * (size_t)i + 1], dirs[3 * (size_t)i + 2]);
+        Rng rng(seed, i, 0, 0);
+        for (uint32_t k = 0; k < skip; ++k) (void)rng.next_f64();
+        value[i] = n_comp == 1 ? mix.pdfs[0].value(dir) : mix.value(dir);
+        const V3 g = n_comp == 1 ? mix.pdfs[0].generate(rng) : mix.generate(rng);
+        generated[3 * (size_t)i] = g.x; generated[3 * (size_t)i + 1] = g.y; generated[3 * (size_t)i + 2] = g.z;
+    }
+    return 0;
+}
 // f64 division / sqrt reference values for the device IEEE check (tests/test_gpu_ieee.py)
 void orc_div_sqrt(uint32_t n, const double* a, const double* b, double* q, double* s) {
     for (uint32_t i = 0; i < n; ++i) { q[i] = a[i] / b[i]; s[i] = std::sqrt(a[i]); }

@@ -169,6 +169,22 @@ struct Pdf {
     }
 };
 
+// MixturePDF with MixtureMethod::Uniform (pdf.rs:185-224).  The PowerHeuristic arm is todo!() in the reference, and no
+// integrator instantiates MixturePDF; restated because it is part of the PDF set.
+struct MixturePdf {
+    std::vector<Pdf> pdfs;
+    double value(V3 direction) const {   // pdf.rs:199-210: weight = 1 / len; map(value * weight).sum()
+        const double weight = 1.0 / (double)pdfs.size();
+        double sum = 0.0;
+        for (const Pdf& p : pdfs) sum = sum + (p.value(direction) * weight);
+        return sum;
+    }
+    V3 generate(Rng& rng) const {        // pdf.rs:212-222: choose(rng).generate(rng).normalize()
+        const Pdf& p = pdfs[rng.index((uint32_t)pdfs.size())];
+        return normalize(p.generate(rng));
+    }
+};
+
 // ---------------------------------------------------------------------------------------------
 // renderer/src/hit.rs, renderer/src/material.rs
 // ---------------------------------------------------------------------------------------------

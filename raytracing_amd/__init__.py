@@ -17,6 +17,8 @@ INTEGRATORS = {"mis": INT_MIS, "light_is": INT_LIGHT_IS, "brdf": INT_BRDF, "unif
 NONE = 0xFFFFFFFF
 RENDER_COUNT_TESTS, RENDER_NO_SORT, RENDER_ONE_LANE = 1, 2, 4
 NOALLOC_MAX_RAYS = 262144
+PDF_COSINE, PDF_UNIFORM_HEMI, PDF_UNIFORM_SPHERE, PDF_FUZZY, PDF_DIELECTRIC, PDF_CONE = range(6)
+PDF_DESC = np.dtype([("kind", "<u4"), ("cannot_refract", "<u4"), ("a", "<f8", 3), ("b", "<f8", 3), ("s", "<f8")])   # rt_pdf_desc, 64 B
 
 
 class RtError(RuntimeError):
@@ -140,6 +142,16 @@ class Context:
     def resolve(self, accum_ptr, width, height, spp, tonemap, out_ptr):
         _hip_check(_ffi.hip().rt_resolve(self._h, C.c_void_p(accum_ptr), width, height, spp, int(tonemap), C.c_void_p(out_ptr)))
 
+    def pdf_eval(self, descs, dirs, seed=0x5EED):
+        """PDF::value / PDF::generate for descs (n x n_comp structured array of PDF_DESC; n_comp > 1 = MixturePDF Uniform) and dirs (n x 3)."""
+        descs = np.ascontiguousarray(descs, PDF_DESC)
+        descs = descs.reshape(len(descs), -1)
+        n, n_comp = descs.shape
+        dirs = np.ascontiguousarray(dirs, np.float64).reshape(n, 3)
+        value = np.empty(n); gen = np.empty((n, 3))
+        _hip_check(_ffi.hip().rt_pdf_eval(self._h, n, n_comp, descs.ctypes.data, dirs.ctypes.data, seed, value.ctypes.data, gen.ctypes.data))
+        return value, gen
+
     def ieee_div_sqrt(self, a, b):
         a = np.ascontiguousarray(a, np.float64); b = np.ascontiguousarray(b, np.float64)
         q = np.empty_like(a); s = np.empty_like(a)
@@ -191,6 +203,17 @@ class GpuScene:
         st = Stats()
         _hip_check(_ffi.hip().rt_render(self._h, C.byref(p), C.c_void_p(accum_ptr), C.byref(st)))
         return st
+
+    def capture_rays(self, width, height, sample, max_depth, integrator, bounce, shadow, stride, max_n, seed=0x5EED, flags=0):
+        """Every stride-th ray of the render loop's queue at `bounce` (shadow rays if shadow) for one sample of every pixel, with the
+        loop's own traversal result: (rays n x 7, prim, inst, t, t_light, queue length)."""
+        p = self._params(width, height, sample, sample + 1, max_depth, integrator, seed, 0, flags)
+        rays = np.empty((max_n, 7)); prim = np.empty(max_n, np.uint32); inst = np.empty(max_n, np.uint32); t = np.empty(max_n); tl = np.empty(max_n)
+        n, qlen = _ffi.u32(), _ffi.u32()
+        _hip_check(_ffi.hip().rt_capture_rays(self._h, C.byref(p), bounce, int(bool(shadow)), stride, max_n, C.byref(n), C.byref(qlen), rays.ctypes.data,
+                                              prim.ctypes.data, inst.ctypes.data, t.ctypes.data, tl.ctypes.data))
+        k = n.value
+        return rays[:k].copy(), prim[:k].copy(), inst[:k].copy(), t[:k].copy(), tl[:k].copy(), qlen.value
 
     def render_host(self, width, height, spp_begin, spp_end, max_depth, integrator, seed=0x5EED, samples_per_pass=0, flags=0):
         p = self._params(width, height, spp_begin, spp_end, max_depth, integrator, seed, samples_per_pass, flags)

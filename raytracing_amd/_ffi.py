@@ -23,7 +23,8 @@ class RenderParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays", u64), ("paths", u64), ("box_tests", u64), ("tri_tests", u64), ("sphere_tests", u64),
                 ("launches", u64), ("ms_total", f64), ("ms_trace", f64), ("ms_shade", f64), ("ms_other", f64),
-                ("trace_launches", u64), ("trace_wave_steps", u64), ("filter_violations", u64)]
+                ("trace_launches", u64), ("trace_wave_steps", u64), ("filter_violations", u64),
+                ("ms_trace_shadow", f64), ("trace_shadow_launches", u64), ("shadow_rays", u64), ("samples_per_pass", u32), ("lanes", u32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -112,20 +113,22 @@ def hip():
         L.rt_trace_closest_device_noalloc.argtypes = [C.c_void_p, u32, C.c_void_p, f64, f64, C.c_void_p, C.c_void_p]
         L.rt_primary_rays.argtypes = [C.c_void_p, u32, u32, u32, u64, C.c_void_p]
         L.rt_render.argtypes = [C.c_void_p, P(RenderParams), C.c_void_p, P(Stats)]
+        L.rt_capture_rays.argtypes = [C.c_void_p, P(RenderParams), u32, C.c_int, u32, u32, P(u32), P(u32), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_accum_zero.argtypes = [C.c_void_p, C.c_void_p, u32, u32]
         L.rt_render_host.argtypes = [C.c_void_p, P(RenderParams), C.c_void_p, P(Stats)]
         L.rt_resolve.argtypes = [C.c_void_p, C.c_void_p, u32, u32, u32, C.c_int, C.c_void_p]
         L.rt_resolve_host.argtypes = [C.c_void_p, u32, u32, u32, C.c_int, C.c_void_p]
         L.rt_sample_radiance.argtypes = [C.c_void_p, u32, u32, u32, C.c_void_p, C.c_void_p, i32, i32, u64, C.c_void_p]
+        L.rt_pdf_eval.argtypes = [C.c_void_p, u32, u32, C.c_void_p, C.c_void_p, u64, C.c_void_p, C.c_void_p]
         L.rt_ieee_div_sqrt.argtypes = [C.c_void_p, u32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _hip = L
     return _hip
 
 
 ABI_SYMBOLS = ["rt_device_count", "rt_context_create", "rt_context_destroy", "rt_context_synchronize", "rt_scene_upload",
-               "rt_scene_destroy", "rt_stream_build_host", "rt_stream_build_prod_host", "rt_prune_info_host", "rt_trace_closest", "rt_trace_closest_device", "rt_trace_closest_device_noalloc", "rt_primary_rays", "rt_render",
+               "rt_scene_destroy", "rt_stream_build_host", "rt_stream_build_prod_host", "rt_prune_info_host", "rt_trace_closest", "rt_trace_closest_device", "rt_trace_closest_device_noalloc", "rt_primary_rays", "rt_render", "rt_capture_rays",
                "rt_accum_zero", "rt_render_host", "rt_resolve", "rt_resolve_host", "rt_sample_radiance",
-               "rt_ieee_div_sqrt", "rt_last_error"]
+               "rt_pdf_eval", "rt_ieee_div_sqrt", "rt_last_error"]
 HOST_SYMBOLS = ["rth_set_bvh_axis_seed", "rth_scene_builtin", "rth_scene_from_description", "rth_scene_free",
                 "rth_scene_describe", "rth_scene_flatten", "rth_scene_object_count", "rth_write_ppm", "rth_write_pfm", "rth_write_png",
                 "rth_image_get_tile", "rth_tile_get_xy", "rth_image_merge_tile", "rth_mat4_inverse",

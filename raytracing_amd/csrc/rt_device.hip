@@ -473,8 +473,14 @@ struct RayS { d3 o, d; double time; };  // ray as handed to this traversal level
 // paths (a few percent of the steps) fetch the f64 ray again instead of holding 14 VGPRs per lane for it:
 // the top level parks it in LDS (14 KB per block; volatile reads stay inside the rare blocks), an instance
 // level keeps the transformed ray it was handed in registers.
-struct RayFromLds {
-    lptr<volatile double> slot;  // &lds[threadIdx.x]; component c at slot[c * 256]; 7..9 = 1/d (bounding_box.rs:29), computed once per ray
+// SHADOW flavours (MIS visibility rays, integrator.rs:82-86): the caller only needs to know whether the closest hit lies within
+// 1e-4 of t_light = light.hit(ray).t, so a lane stops as soon as it ACCEPTS a hit with RN(t - t_light) < -1e-4: up to that
+// accept its walk is the reference's own (same tests, same running best), the reference's final t can only be smaller, and
+// rounding is monotone -- |t_final - t_light| > 1e-4 whatever comes after.  tl() is that ray's t_light.
+template <bool SHADOW_> struct RayFromLdsT {
+    static constexpr bool SHADOW = SHADOW_;
+    lptr<volatile double> slot;  // &lds[threadIdx.x]; component c at slot[c * 256]; 7..9 = 1/d (bounding_box.rs:29), computed once per ray; 10 = t_light (SHADOW)
+    RT_DEV double tl() const { return slot[10 * 256]; }
     RT_DEV RayS get() const {
         RayS r;
         r.o = mk(slot[0 * 256], slot[1 * 256], slot[2 * 256]);
@@ -484,12 +490,17 @@ struct RayFromLds {
     }
     RT_DEV d3 inv() const { return mk(slot[7 * 256], slot[8 * 256], slot[9 * 256]); }
 };
-struct RayInRegisters {
+typedef RayFromLdsT<false> RayFromLds;
+template <bool SHADOW_> struct RayInRegistersT {
+    static constexpr bool SHADOW = SHADOW_;
     RayS r;
     d3 rinv;
+    double t_light;
+    RT_DEV double tl() const { return t_light; }
     RT_DEV RayS get() const { return r; }
     RT_DEV d3 inv() const { return rinv; }
 };
+typedef RayInRegistersT<false> RayInRegisters;
 
 template <int LEVEL, bool COUNT, bool INST, class RAYSRC, class HIT>
 RT_DEV void traverse(const SceneDev& sc, uint32_t first, const RAYSRC& src, HIT& h, bool active, double t_min, uint32_t inst_prim, LaneCount& cnt);
@@ -631,7 +642,7 @@ RT_DEV lanemask box_step(const Window& w, const BoxFilter& bf, const PruneState&
 // Exact f64 tests of a TRI2 leaf for the lanes of m_pass the filter did not reject (COUNT: for every lane of m_pass),
 // one triangle at a time (register pressure); the f64 ray is re-derived here rather than kept live across the hot loop.
 template <bool COUNT, int MODE, class RAYSRC, class HIT>
-RT_DEV void tri2_exact(const SceneDev& sc, uint32_t node, uint32_t rec_off, lanemask m_pass, lanemask rejA, lanemask rejB, const RAYSRC& src, uint32_t cur_xf, HIT& h,
+RT_DEV bool tri2_exact(const SceneDev& sc, uint32_t node, uint32_t rec_off, lanemask m_pass, lanemask rejA, lanemask rejB, const RAYSRC& src, uint32_t cur_xf, HIT& h,
                        double t_min, uint32_t inst_prim, BoxFilter& bf, LaneCount& cnt) {
     cptr<rt_node> nodes = as_const(sc.nodes);
     cptr<rt_geom> geom = as_const(sc.geom);
@@ -662,6 +673,7 @@ RT_DEV void tri2_exact(const SceneDev& sc, uint32_t node, uint32_t rec_off, lane
 #ifdef RT_TRACE_DIAG
     cnt.exact_tri += 1;
 #endif
+    return changed;
 }
 
 template <int LEVEL, bool COUNT, bool INST, int MODE, class RAYSRC, class HIT>
@@ -671,6 +683,24 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
     // nesting argument behind the production form needs NaN-free slab values).  `first`: LEVEL 0 -- unused (the scene range
     // starts at root_off), LEVEL 1 -- first node of the instance's sub-array.
     const bool full = COUNT || MODE == BOX_LITERAL;
+    constexpr bool SHADOW = RAYSRC::SHADOW && LEVEL == 0 && !COUNT;  // the counting kernel walks the reference's complete visited set
+    const uint32_t end_off = full ? sc.end_off_full : sc.end_off;    // the END record of the scene range
+    // A lane whose accepted hit already decides "not visible" waits for the END record; if that was the last lane the walk is over,
+    // otherwise the cursor jumps to the first record any lane still needs.  Only ever reached from wave-uniform control flow.
+#define RT_SHADOW_FINISH(CHANGED)                                                                  \
+    if constexpr (SHADOW) {                                                                        \
+        const bool ch_ = (CHANGED);                                                                \
+        if (__builtin_amdgcn_ballot_w64(ch_) != 0ull) {                                            \
+            const bool fin_ = ch_ && ((double)h.best - src.tl()) < -0.0001;                        \
+            if (__builtin_amdgcn_ballot_w64(fin_) != 0ull) {                                       \
+                wait = fin_ ? end_off : wait;                                                      \
+                const uint32_t nxt_ = wave_min_u32(wait);                                          \
+                if (nxt_ >= end_off) { want = RT_WALK_DONE; break; }                               \
+                off = nxt_ > off ? nxt_ : off;                                                     \
+            }                                                                                      \
+        }                                                                                          \
+        RT_RECONVERGE();                                                                           \
+    }
     const uint32_t* node_off = full ? sc.node_off_full : sc.node_off;
     first = LEVEL == 0 ? (full ? sc.root_off_full : sc.root_off) : as_const(node_off)[first];
     uint32_t wait = active ? first : 0xFFFFFFFFu;
@@ -745,12 +775,14 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
                 const lanemask m_act = mask_reached(off, wait);
                 lanemask rejA, rejB;
                 tri_filter(tf, w, rejA, rejB);
+                bool changed = false;
                 if ((m_act & ~(rejA & rejB)) != 0ull) {
                     const lanemask m_pass = box_step<0, MODE, COUNT>(w, bf, ps, false, off, wait, rec, nodes, src, h, t_min, cnt);
-                    if ((m_pass & ~(rejA & rejB)) != 0ull) tri2_exact<COUNT, MODE>(sc, node, off, m_pass, rejA, rejB, src, cur_xf, h, t_min, inst_prim, bf, cnt);
+                    if ((m_pass & ~(rejA & rejB)) != 0ull) changed = tri2_exact<COUNT, MODE>(sc, node, off, m_pass, rejA, rejB, src, cur_xf, h, t_min, inst_prim, bf, cnt);
                     RT_RECONVERGE();
                 }
                 off += RT_STREAM_REC_TRI2;
+                RT_SHADOW_FINISH(changed)
                 continue;
             }
             lanemask m_pass = box_step<0, MODE, COUNT>(w, bf, ps, (rec & RT_STREAM_KIND) == RT_STREAM_INNER, off, wait, rec, nodes, src, h, t_min, cnt);
@@ -792,6 +824,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
                 }
                 if (MODE == BOX_PLAIN && changed) box_filter_set_best(bf, h.best);
                 RT_RECONVERGE();
+                RT_SHADOW_FINISH(changed)
             } else if ((rec & RT_STREAM_KIND) == RT_STREAM_TRI2) {  // the common leaf: one or two triangles under one transform
                 if (wword<8>(w) != cur_xf) {  // re-enter at this record with the rays in the leaf's space
                     if (COUNT && !(rec & RT_NODE_NO_BOX)) cnt.box -= mask_lane(m_pass) ? 1u : 0u;  // the repeated box test must not count twice
@@ -805,10 +838,12 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
                 }
                 lanemask rejA, rejB;
                 tri_filter(tf, w, rejA, rejB);
+                bool changed = false;
                 if (COUNT || (m_pass & ~(rejA & rejB)) != 0ull) {  // rare: most tested triangles are nowhere near the rays
-                    tri2_exact<COUNT, MODE>(sc, node, off - RT_STREAM_REC_TRI2, m_pass, rejA, rejB, src, cur_xf, h, t_min, inst_prim, bf, cnt);
+                    changed = tri2_exact<COUNT, MODE>(sc, node, off - RT_STREAM_REC_TRI2, m_pass, rejA, rejB, src, cur_xf, h, t_min, inst_prim, bf, cnt);
                     RT_RECONVERGE();
                 }
+                RT_SHADOW_FINISH(changed)
             } else {  // any other leaf: exact tests on the blob's tables
                 if (node == RT_STREAM_END_NODE) { want = RT_WALK_DONE; break; }  // END record: every ray still waiting has arrived at the end of the range
                 const uint32_t p0 = wword<8>(w), p1 = wword<9>(w);
@@ -836,8 +871,10 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
                 }
                 if (MODE == BOX_PLAIN && changed) box_filter_set_best(bf, h.best);
                 RT_RECONVERGE();
+                RT_SHADOW_FINISH(changed)
             }
         }
+#undef RT_SHADOW_FINISH
         if (want == RT_WALK_DONE) break;
         cur_xf = (uint32_t)__builtin_amdgcn_readfirstlane((int)want);
     }
@@ -871,7 +908,8 @@ RT_DEV void traverse(const SceneDev& sc, uint32_t first, const RAYSRC& src, HIT&
 // rays: one 64-byte block per path (ox,oy,oz,dx | dy,dz,time,pad); outputs indexed by path.
 // REGS: keep the f64 ray in registers instead of LDS -- for scenes whose leaves are mostly not triangles, where
 // (almost) every leaf step runs an exact f64 test and would read the ray back from LDS each time.
-template <bool COUNT, bool INST, bool REGS>
+// SHADOW: the rays are MIS visibility rays whose block carries t_light in its last slot; see RayFromLdsT.
+template <bool COUNT, bool INST, bool REGS, bool SHADOW = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : REGS ? RT_TRACE_WAVES_REGS : RT_TRACE_WAVES))) void k_trace(SceneDev sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_fixed,
                                                const double* __restrict__ rays, uint32_t cap, double t_min, double t_max,
                                                uint32_t* __restrict__ out_prim, uint32_t* __restrict__ out_inst, double* __restrict__ out_t,
@@ -885,7 +923,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : 
     const uint32_t slot = wave_first + (tid & 63u);
     const bool valid = (tid & 63u) < lanes && slot < n;
     const uint32_t path = valid ? (queue ? queue[slot] : slot) : 0u;
-    __shared__ double lds_ray[10 * 256];
+    __shared__ double lds_ray[(SHADOW ? 11 : 10) * 256];
     __shared__ double lds_best[256];
     __shared__ uint32_t lds_prim[256], lds_inst[256];
     {
@@ -894,10 +932,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : 
         const double4 a = valid ? r4[0] : make_double4(0.0, 0.0, 0.0, 1.0), b = valid ? r4[1] : make_double4(1.0, 1.0, 0.0, 0.0);
         slot[0 * 256] = a.x; slot[1 * 256] = a.y; slot[2 * 256] = a.z; slot[3 * 256] = a.w; slot[4 * 256] = b.x; slot[5 * 256] = b.y; slot[6 * 256] = b.z;
         slot[7 * 256] = 1.0 / a.w; slot[8 * 256] = 1.0 / b.x; slot[9 * 256] = 1.0 / b.y;
+        if (SHADOW) slot[10 * 256] = b.w;  // t_light (k_shade)
     }
-    RayFromLds src; src.slot = (lptr<volatile double>)&lds_ray[threadIdx.x];  // each lane reads back only its own slot: no barrier needed
-    RayInRegisters src_regs;
-    if (REGS) { src_regs.r = src.get(); src_regs.rinv = src.inv(); }
+    RayFromLdsT<SHADOW> src; src.slot = (lptr<volatile double>)&lds_ray[threadIdx.x];  // each lane reads back only its own slot: no barrier needed
+    RayInRegistersT<SHADOW> src_regs;
+    if (REGS) { src_regs.r = src.get(); src_regs.rinv = src.inv(); src_regs.t_light = SHADOW ? src.tl() : 0.0; }
     LaneHit h;
     h.best.p = (lptr<volatile double>)&lds_best[threadIdx.x]; h.prim.p = (lptr<volatile uint32_t>)&lds_prim[threadIdx.x]; h.inst.p = (lptr<volatile uint32_t>)&lds_inst[threadIdx.x];
     h.best = t_max; h.prim = RT_NONE; h.inst = RT_NONE;
@@ -907,10 +946,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : 
 #endif
     if (REGS) {
         LaneHitRegs hr; hr.best = t_max; hr.prim = RT_NONE; hr.inst = RT_NONE;
-        traverse<0, COUNT, INST, RayInRegisters, LaneHitRegs>(sc, sc.root_off, src_regs, hr, valid, t_min, RT_NONE, cnt);
+        traverse<0, COUNT, INST, RayInRegistersT<SHADOW>, LaneHitRegs>(sc, sc.root_off, src_regs, hr, valid, t_min, RT_NONE, cnt);
         h.best = (double)hr.best; h.prim = (uint32_t)hr.prim; h.inst = (uint32_t)hr.inst;
     } else {
-        traverse<0, COUNT, INST, RayFromLds, LaneHit>(sc, sc.root_off, src, h, valid, t_min, RT_NONE, cnt);
+        traverse<0, COUNT, INST, RayFromLdsT<SHADOW>, LaneHit>(sc, sc.root_off, src, h, valid, t_min, RT_NONE, cnt);
     }
 #ifdef RT_TRACE_DIAG
     cnt.cyc_total = __builtin_readcyclecounter() - cnt.cyc_total;
@@ -1046,7 +1085,7 @@ RT_DEV uint32_t sort_key(const SceneDev& sc, d3 o, d3 d) {
     return ((morton >> 9) << 18) | (oct << 15) | ((morton & 0x1FFu) << 6) | dbin;
 #endif
 }
-#define RT_SORT_BITS 25u  /* 24 key bits (+ one spare): octant | origin cell | direction bin */
+#define RT_SORT_BITS 24u  /* octant (3) | origin cell (12) | direction bin (9): three 8-bit digit passes */
 
 RT_DEV void push_queue_keyed(bool want, uint32_t path, uint32_t key, uint32_t* __restrict__ queue, uint32_t* __restrict__ keys, uint32_t* __restrict__ count) {
     const uint64_t m = __ballot(want);
@@ -1152,7 +1191,7 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, PathBuffers pb, cons
                             double light_cos_theta = fmax(dot(hr.normal, light_dir), 0.0);
                             c_l = material_brdf(sc, mat, hr, light_dir) * light_cos_theta * light_emit * light_weight / light_pdf_value;
                             double4* s4 = (double4*)(pb.shadow_rays + (size_t)path * RT_RAY_STRIDE);
-                            s4[0] = make_double4(hr.point.x, hr.point.y, hr.point.z, light_dir.x); s4[1] = make_double4(light_dir.y, light_dir.z, ray.time, 0.0);
+                            s4[0] = make_double4(hr.point.x, hr.point.y, hr.point.z, light_dir.x); s4[1] = make_double4(light_dir.y, light_dir.z, ray.time, t_light);  // last slot: t_light for the visibility walk's early exit
                             want_shadow = true;
                             shadow_key = sort_key(sc, hr.point, light_dir);
                         }
@@ -1273,6 +1312,24 @@ __global__ void k_iota(uint32_t* q, uint32_t n) {
     if (i < n) q[i] = i;
 }
 __global__ void k_set_u32(uint32_t* p, uint32_t v) { *p = v; }
+// rt_pdf_eval: PDF::value / PDF::generate of pdf.rs for n independent items, each a list of n_comp PDFs (n_comp > 1: MixturePDF Uniform)
+#define RT_PDF_MAX_COMP 8u
+__global__ __launch_bounds__(256) void k_pdf_eval(uint32_t n, uint32_t n_comp, const rt_pdf_desc* __restrict__ descs, const double* __restrict__ dirs, uint64_t seed,
+                                                 double* __restrict__ value, double* __restrict__ generated) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Pdf pdfs[RT_PDF_MAX_COMP];
+    for (uint32_t c = 0; c < n_comp; ++c) {
+        const rt_pdf_desc d = descs[(size_t)i * n_comp + c];
+        pdfs[c].kind = (int)d.kind; pdfs[c].a = ld3(d.a); pdfs[c].b = ld3(d.b); pdfs[c].s = d.s; pdfs[c].cannot_refract = d.cannot_refract != 0u;
+    }
+    const d3 dir = ld3(dirs + 3 * (size_t)i);
+    Rng rng(seed, i, 0u, 0u);
+    const double v = n_comp == 1u ? pdf_value(pdfs[0], dir) : pdf_mixture_value(pdfs, n_comp, dir);
+    const d3 g = n_comp == 1u ? pdf_generate(pdfs[0], rng) : pdf_mixture_generate(pdfs, n_comp, rng);
+    value[i] = v;
+    generated[3 * (size_t)i] = g.x; generated[3 * (size_t)i + 1] = g.y; generated[3 * (size_t)i + 2] = g.z;
+}
 __global__ void k_div_sqrt(uint32_t n, const double* a, const double* b, double* q, double* s) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { q[i] = a[i] / b[i]; s[i] = __builtin_sqrt(a[i]); }
@@ -1404,13 +1461,14 @@ struct EventTimer {
         spans.clear();
     }
 };
-enum { CAT_TRACE = 0, CAT_SHADE = 1, CAT_OTHER = 2, CAT_N = 3 };
+enum { CAT_TRACE = 0, CAT_SHADE = 1, CAT_OTHER = 2, CAT_SHADOW = 3, CAT_N = 4 };  // CAT_SHADOW: traversal launches of MIS shadow rays (integrator.rs:82)
 
 static void launch_trace(rt_scene* sc, unsigned long long* lstats, uint32_t lcap, hipStream_t st, bool count, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_bound, const double* rays, double t_min,
-                         double t_max, uint32_t* out_prim, uint32_t* out_inst, double* out_t, uint32_t lanes = 64u, uint32_t t_stride = 1u, PathHit* out_hit = nullptr) {
+                         double t_max, uint32_t* out_prim, uint32_t* out_inst, double* out_t, uint32_t lanes = 64u, uint32_t t_stride = 1u, PathHit* out_hit = nullptr, bool shadow = false) {
     if (n_bound == 0) return;
     const dim3 grid((uint32_t)((((uint64_t)n_bound + lanes - 1u) / lanes + 3u) / 4u));  // waves of `lanes` rays, four waves per block
-#define RT_LAUNCH_TRACE_R(C, I, R) hipLaunchKernelGGL((k_trace<C, I, R>), grid, dim3(256), 0, st, sc->dev, queue, n_ptr, n_bound, rays, lcap, t_min, t_max, out_prim, out_inst, out_t, lstats, lanes, t_stride, out_hit)
+#define RT_LAUNCH_TRACE_S(C, I, R, S) hipLaunchKernelGGL((k_trace<C, I, R, S>), grid, dim3(256), 0, st, sc->dev, queue, n_ptr, n_bound, rays, lcap, t_min, t_max, out_prim, out_inst, out_t, lstats, lanes, t_stride, out_hit)
+#define RT_LAUNCH_TRACE_R(C, I, R) do { if (shadow && !C) RT_LAUNCH_TRACE_S(C, I, R, !C); else RT_LAUNCH_TRACE_S(C, I, R, false); } while (0)
 #define RT_LAUNCH_TRACE(C, I) do { if (sc->reg_ray) RT_LAUNCH_TRACE_R(C, I, true); else RT_LAUNCH_TRACE_R(C, I, false); } while (0)
     const bool inst = sc->has_instances;  // scenes without BVHNode objects use the kernel variant compiled without the nested walk
 #ifdef RT_TRACE_DIAG
@@ -1420,6 +1478,7 @@ static void launch_trace(rt_scene* sc, unsigned long long* lstats, uint32_t lcap
 #endif
     if (count) { if (inst) RT_LAUNCH_TRACE(true, true); else RT_LAUNCH_TRACE(true, false); }
     else { if (inst) RT_LAUNCH_TRACE(false, true); else RT_LAUNCH_TRACE(false, false); }
+#undef RT_LAUNCH_TRACE_S
 #undef RT_LAUNCH_TRACE_R
 #undef RT_LAUNCH_TRACE
 #ifdef RT_TRACE_DIAG
@@ -1450,8 +1509,37 @@ static int sort_queue(Workspace& ws, hipStream_t st, uint32_t n, uint32_t* keys_
     return RT_OK;
 }
 
+// rt_capture_rays: copies out every stride-th ray of one queue of the render loop, with what the loop's own traversal launch reported for it
+struct Capture {
+    uint32_t bounce = 0; bool shadow = false; uint32_t stride = 1, max_n = 0;
+    std::vector<double> rays, t, t_light; std::vector<uint32_t> prim, inst;
+    uint32_t queue_len = 0;
+};
+static int capture_queue(Workspace& ws, hipStream_t st, const uint32_t* queue, uint32_t live, const double* rays_dev, const PathHit* hit_dev, const double* rec_dev, Capture& cap) {
+    HIP_OK(hipStreamSynchronize(st));
+    cap.queue_len = live;
+    std::vector<uint32_t> q(live);
+    HIP_OK(hipMemcpy(q.data(), queue, (size_t)live * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (uint32_t k = 0; k < live && cap.prim.size() < cap.max_n; k += cap.stride) {
+        const uint32_t path = q[k];
+        double r[8];
+        HIP_OK(hipMemcpy(r, rays_dev + (size_t)path * RT_RAY_STRIDE, sizeof r, hipMemcpyDeviceToHost));
+        for (int c = 0; c < 7; ++c) cap.rays.push_back(r[c]);
+        if (hit_dev) {   // path rays: the hit record k_shade will consume (indexed by queue slot)
+            PathHit ph;
+            HIP_OK(hipMemcpy(&ph, hit_dev + k, sizeof ph, hipMemcpyDeviceToHost));
+            cap.prim.push_back(ph.prim); cap.inst.push_back(ph.inst); cap.t.push_back(ph.t); cap.t_light.push_back(0.0);
+        } else {         // shadow rays: t_light travels in the ray block, the walk's t goes to the bounce record
+            double ts;
+            HIP_OK(hipMemcpy(&ts, rec_dev + (size_t)path * REC_STRIDE, sizeof ts, hipMemcpyDeviceToHost));
+            cap.prim.push_back(RT_NONE); cap.inst.push_back(RT_NONE); cap.t.push_back(ts); cap.t_light.push_back(r[7]);
+        }
+    }
+    return RT_OK;
+}
+
 static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bool explicit_lists, uint32_t width, uint32_t height, uint32_t sample0, int32_t max_depth,
-                     int32_t integrator, uint64_t seed, bool count_tests, bool sort_rays, EventTimer& tm, uint64_t& launches) {
+                     int32_t integrator, uint64_t seed, bool count_tests, bool sort_rays, EventTimer& tm, uint64_t& launches, uint64_t* shadow_rays = nullptr, Capture* cap = nullptr) {
     const uint32_t npix = width * height;
     tm.begin(CAT_OTHER);
     hipLaunchKernelGGL(k_raygen, grid_for(n), dim3(256), 0, st, sc->dev.camera, width, height, n, sample0, npix,
@@ -1471,6 +1559,7 @@ static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bo
         tm.begin(CAT_TRACE);
         launch_trace(sc, ws.stats, ws.cap, st, count_tests, ws.queue[cur], ws.counts + cur, live, ws.pb.rays, 0.001, 100000.0, nullptr, nullptr, nullptr, 64u, 1u, ws.pb.hit);  // integrator.rs:38
         tm.end();
+        if (cap && !cap->shadow && (uint32_t)bounce == cap->bounce) return capture_queue(ws, st, ws.queue[cur], live, ws.pb.rays, ws.pb.hit, nullptr, *cap);
         const bool mis_shadow = integrator == RT_INT_MIS && sc->dev.n_lights > 0;
         const bool last_bounce = bounce + 1 >= max_depth;
         tm.begin(CAT_SHADE);
@@ -1493,11 +1582,14 @@ static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bo
         tm.end();
         launches += 2;
         if (mis_shadow && shadow_live) {
-            tm.begin(CAT_TRACE);
+            if (shadow_rays) *shadow_rays += shadow_live;
+            tm.begin(CAT_SHADOW);
             launch_trace(sc, ws.stats, ws.cap, st, count_tests, ws.shadow_queue, ws.counts + 2, shadow_live, ws.pb.shadow_rays, 0.001, 10000.0, nullptr, nullptr,
-                         ws.pb.records + (size_t)bounce * ws.cap * REC_STRIDE + REC_T_SHADOW, 64u, (uint32_t)REC_STRIDE);  // integrator.rs:82
+                         ws.pb.records + (size_t)bounce * ws.cap * REC_STRIDE + REC_T_SHADOW, 64u, (uint32_t)REC_STRIDE, nullptr, true);  // integrator.rs:82
             tm.end();
             launches += 1;
+            if (cap && cap->shadow && (uint32_t)bounce == cap->bounce)
+                return capture_queue(ws, st, ws.shadow_queue, shadow_live, ws.pb.shadow_rays, nullptr, ws.pb.records + (size_t)bounce * ws.cap * REC_STRIDE + REC_T_SHADOW, *cap);
         }
         cur = nxt;
         live = next_live;
@@ -2211,6 +2303,7 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     v.texels = d + h.off_texels; v.lights = (const rt_light*)(d + h.off_lights);
     v.mat_uses_uv = sc->d_mat_uses_uv;
     v.stream = sc->d_stream; v.root_off = P.root_off_prod;
+    v.end_off = P.end_off_prod[h.root_end]; v.end_off_full = P.end_off[h.root_end];
     v.stream_full = sc->d_stream_full; v.node_off_full = sc->d_node_off_full; v.root_off_full = P.root_off;
     v.node_off = sc->d_node_off; v.box_abs_max = box_abs_max;
     v.cert_cells = sc->d_cert_cells; v.cert_entries = sc->d_cert_entries; v.cert_normals = sc->d_cert_normals;
@@ -2388,17 +2481,13 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
     // samples, so that both lanes have work.  The counting kernel runs on one lane (same passes, same sums).
     uint32_t spass = p->samples_per_pass;
     if (spass == 0) {
-        size_t free_b = 0, total_b = 0;
-        HIP_OK(hipMemGetInfo(&free_b, &total_b));
-        for (const Workspace* w : {&sc->ws, &sc->ws2})  // what the lanes already hold counts as free: it is re-used or released
-            free_b += (size_t)w->cap * ((size_t)std::max(w->depth, 1) * REC_STRIDE * 8 + 320);
-        const uint64_t budget = std::min<uint64_t>(96ull << 30, (uint64_t)free_b / 3);
-        uint64_t by_paths = std::max<uint64_t>(1, (128ull << 20) / npix);
-        uint64_t by_mem = std::max<uint64_t>(1, budget / ((uint64_t)npix * ((uint64_t)p->max_depth * REC_STRIDE * 8 + 320)));
-        // path buffers of a previous call that are at least half the ideal size are kept as they are: the estimate moves by a
-        // sample from call to call, and re-allocating ~100 GB per call costs more than any pass size gains
-        const uint64_t have = (sc->ws.depth >= p->max_depth) ? sc->ws.cap / npix : 0;
-        if (have >= 1 && have * 2 >= std::min(by_mem, by_paths)) by_mem = by_paths = have;
+        // A pure function of the parameters (never of free memory or of earlier calls): pass boundaries decide the order of
+        // the fp32 additions into the accumulator, so resumed, chunked and sharded renders of the same samples must cut the
+        // same passes to stay bit-identical.  Budget: 80 GiB of path state per lane (two lanes + scene fit the 288 GB), at most
+        // 128M paths, at most half the call's samples so that both lanes have work.  If the buffers do not fit (a shared GPU),
+        // the call fails with RT_ERR_OOM and the caller chooses samples_per_pass itself.
+        const uint64_t by_paths = std::max<uint64_t>(1, (128ull << 20) / npix);
+        const uint64_t by_mem = std::max<uint64_t>(1, (80ull << 30) / ((uint64_t)npix * ((uint64_t)p->max_depth * REC_STRIDE * 8 + 320)));
         spass = (uint32_t)std::min<uint64_t>(std::min(by_paths, by_mem), 256);
         spass = std::min(spass, (spp + 1u) / 2u);
     }
@@ -2420,7 +2509,7 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
     }
 
     struct LaneRun {
-        Workspace* ws; hipStream_t st; EventTimer tm; uint64_t launches = 0; int rc = RT_OK; std::string err;
+        Workspace* ws; hipStream_t st; EventTimer tm; uint64_t launches = 0, shadow_rays = 0; int rc = RT_OK; std::string err;
         LaneRun(Workspace* w, hipStream_t s, bool timed) : ws(w), st(s), tm(s, timed) {}
     };
     LaneRun lane[2] = {LaneRun(&sc->ws, st, stats != nullptr), LaneRun(&sc->ws2, sc->stream2, stats != nullptr)};
@@ -2440,7 +2529,7 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
         for (uint32_t k = (uint32_t)li; k < n_pass; k += (uint32_t)n_lanes) {
             const uint32_t s0 = p->spp_begin + k * spass;
             const uint32_t ns = std::min(spass, p->spp_end - s0);
-            int r = run_paths(sc, ws, L.st, npix * ns, false, p->width, p->height, s0, p->max_depth, p->integrator, p->seed, count_tests, sort_rays, L.tm, L.launches);
+            int r = run_paths(sc, ws, L.st, npix * ns, false, p->width, p->height, s0, p->max_depth, p->integrator, p->seed, count_tests, sort_rays, L.tm, L.launches, &L.shadow_rays);
             if (r != RT_OK) return r;
             if (k > 0) {
                 std::unique_lock<std::mutex> lk(mu);
@@ -2492,20 +2581,54 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
     if (stats && rc == RT_OK) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, e0, e1);
-        double by_cat[CAT_N] = {0, 0, 0}; uint64_t n_by_cat[CAT_N] = {0, 0, 0};
+        double by_cat[CAT_N] = {0, 0, 0, 0}; uint64_t n_by_cat[CAT_N] = {0, 0, 0, 0};
         for (int li = 0; li < n_lanes; ++li) lane[li].tm.collect(by_cat, CAT_N, n_by_cat);
         for (int k = 0; k < 16; ++k) st4[k] += st4b[k];
         stats->rays = st4[0]; stats->box_tests = st4[1]; stats->tri_tests = st4[2]; stats->sphere_tests = st4[3];
         stats->paths = (uint64_t)npix * spp; stats->launches = lane[0].launches + lane[1].launches;
-        stats->ms_total = ms; stats->ms_trace = by_cat[CAT_TRACE]; stats->ms_shade = by_cat[CAT_SHADE]; stats->ms_other = by_cat[CAT_OTHER];
-        stats->trace_launches = n_by_cat[CAT_TRACE]; stats->filter_violations = st4[13]; stats->trace_wave_steps = st4[15];
+        stats->ms_total = ms; stats->ms_trace = by_cat[CAT_TRACE] + by_cat[CAT_SHADOW]; stats->ms_shade = by_cat[CAT_SHADE]; stats->ms_other = by_cat[CAT_OTHER];
+        stats->trace_launches = n_by_cat[CAT_TRACE] + n_by_cat[CAT_SHADOW]; stats->filter_violations = st4[13]; stats->trace_wave_steps = st4[15];
+        stats->ms_trace_shadow = by_cat[CAT_SHADOW]; stats->trace_shadow_launches = n_by_cat[CAT_SHADOW];
+        stats->shadow_rays = lane[0].shadow_rays + lane[1].shadow_rays; stats->samples_per_pass = spass; stats->lanes = (uint32_t)n_lanes;
     } else {
-        double by_cat[CAT_N] = {0, 0, 0}; uint64_t n_by_cat[CAT_N] = {0, 0, 0};
+        double by_cat[CAT_N] = {0, 0, 0, 0}; uint64_t n_by_cat[CAT_N] = {0, 0, 0, 0};
         for (int li = 0; li < n_lanes; ++li) lane[li].tm.collect(by_cat, CAT_N, n_by_cat);   // releases the events
     }
     for (auto& e : added) (void)hipEventDestroy(e);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e_lane2);
     return rc;
+}
+
+int rt_capture_rays(rt_scene* sc, const rt_render_params* p, uint32_t bounce, int shadow, uint32_t stride, uint32_t max_n, uint32_t* n_out, uint32_t* queue_len,
+                    double* rays, uint32_t* prim_id, uint32_t* inst_id, double* t, double* t_light) {
+    if (!sc || !n_out || !rays || !prim_id || !inst_id || !t || !t_light || stride == 0) return fail(RT_ERR_BAD_ARG, "rt_capture_rays: bad argument");
+    int rc = check_params(p);
+    if (rc != RT_OK) return rc;
+    if (p->spp_end != p->spp_begin + 1) return fail(RT_ERR_BAD_ARG, "rt_capture_rays: exactly one sample index");
+    if ((int32_t)bounce >= p->max_depth) return fail(RT_ERR_BAD_ARG, "rt_capture_rays: bounce >= max_depth");
+    HIP_OK(hipSetDevice(sc->ctx->device));
+    const uint32_t npix = p->width * p->height;
+    rc = ws_ensure(sc, sc->ws, npix, p->max_depth);
+    if (rc != RT_OK) return rc;
+    Capture cap; cap.bounce = bounce; cap.shadow = shadow != 0; cap.stride = stride; cap.max_n = max_n;
+    EventTimer tm(sc->ctx->stream, false);
+    uint64_t launches = 0;
+    HIP_OK(hipMemsetAsync(sc->ws.stats, 0, 16 * sizeof(unsigned long long), sc->ctx->stream));
+    rc = run_paths(sc, sc->ws, sc->ctx->stream, npix, false, p->width, p->height, p->spp_begin, p->max_depth, p->integrator, p->seed, false,
+                   (p->flags & RT_RENDER_NO_SORT) == 0 && sc->sortable, tm, launches, nullptr, &cap);
+    HIP_OK(hipStreamSynchronize(sc->ctx->stream));
+    if (rc != RT_OK) return rc;
+    const uint32_t n = (uint32_t)cap.prim.size();
+    *n_out = n; if (queue_len) *queue_len = cap.queue_len;
+    memcpy(rays, cap.rays.data(), (size_t)n * 7 * sizeof(double));
+    memcpy(t, cap.t.data(), (size_t)n * sizeof(double)); memcpy(t_light, cap.t_light.data(), (size_t)n * sizeof(double));
+    for (uint32_t i = 0; i < n; ++i) {   // object ids, as rt_trace_closest reports them
+        if (cap.prim[i] == RT_NONE) { prim_id[i] = RT_NONE; inst_id[i] = RT_NONE; continue; }
+        const rt_prim& q = sc->host_prims[cap.prim[i]];
+        prim_id[i] = q.object_id;
+        inst_id[i] = cap.inst[i] != RT_NONE ? sc->host_prims[cap.inst[i]].inst_id : q.inst_id;
+    }
+    return RT_OK;
 }
 
 int rt_render_host(rt_scene* sc, const rt_render_params* p, float* accum_host, rt_stats* stats) {
@@ -2579,6 +2702,30 @@ int rt_sample_radiance(rt_scene* sc, uint32_t width, uint32_t height, uint32_t n
     HIP_OK(hipStreamSynchronize(st));
     for (uint32_t i = 0; i < n; ++i)
         for (int c = 0; c < 3; ++c) out_rgb[(size_t)i * 3 + c] = rad[(size_t)c * ws.cap + i];
+    return RT_OK;
+}
+
+int rt_pdf_eval(rt_context* ctx, uint32_t n, uint32_t n_comp, const rt_pdf_desc* pdfs, const double* dirs, uint64_t seed, double* value, double* generated) {
+    if (!ctx || (n && (!pdfs || !dirs || !value || !generated))) return fail(RT_ERR_BAD_ARG, "rt_pdf_eval: null argument");
+    if (n_comp < 1 || n_comp > RT_PDF_MAX_COMP) return fail(RT_ERR_BAD_ARG, "rt_pdf_eval: n_comp must be 1..8");
+    for (size_t k = 0; k < (size_t)n * n_comp; ++k)
+        if (pdfs[k].kind > RT_PDF_CONE) return fail(RT_ERR_BAD_ARG, "rt_pdf_eval: unknown PDF kind");
+    if (n == 0) return RT_OK;
+    HIP_OK(hipSetDevice(ctx->device));
+    const size_t b_desc = (size_t)n * n_comp * sizeof(rt_pdf_desc), b_dir = (size_t)n * 3 * sizeof(double), b_val = (size_t)n * sizeof(double);
+    uint8_t* d = nullptr;
+    HIP_OK(hipMalloc((void**)&d, b_desc + 2 * b_dir + b_val));
+    rt_pdf_desc* d_desc = (rt_pdf_desc*)d; double* d_dir = (double*)(d + b_desc); double* d_gen = d_dir + (size_t)n * 3; double* d_val = d_gen + (size_t)n * 3;
+    hipError_t e = hipMemcpy(d_desc, pdfs, b_desc, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_dir, dirs, b_dir, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_pdf_eval, grid_for(n), dim3(256), 0, ctx->stream, n, n_comp, d_desc, d_dir, seed, d_val, d_gen);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(value, d_val, b_val, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(generated, d_gen, b_dir, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, hipGetErrorString(e));
     return RT_OK;
 }
 

@@ -43,6 +43,7 @@ struct SceneDev {
     double prune_time0, prune_time1;  // covered moving spheres are boxed over this shutter; rays outside it are not pruned
     uint32_t prune_on, prune_xf, cert_n_normals;
     uint32_t root_off;  // first scene-level record in `stream` (the range is closed by an END record)
+    uint32_t end_off, end_off_full;  // that END record's offset in `stream` / `stream_full`
     rt_camera camera;
     uint32_t n_lights, root_node, root_end, background;
     uint32_t n_nodes, boxes_finite;
@@ -314,6 +315,19 @@ RT_DEV d3 pdf_generate(const Pdf& p, Rng& rng) {
             return onb_local(b, mk(cs * sin_theta, sn * sin_theta, cos_theta));
         }
     }
+}
+// MixturePDF, MixtureMethod::Uniform (pdf.rs:185-224; the PowerHeuristic arm is todo!() in the reference): value = sum of
+// value_i * (1 / n) in list order (Iterator::sum folds from 0.0), generate = one uniformly chosen member's direction, normalised.
+// No integrator of the reference instantiates it; it is part of the PDF set and checked through rt_pdf_eval.
+RT_DEV double pdf_mixture_value(const Pdf* pdfs, uint32_t n, d3 direction) {
+    const double weight = 1.0 / (double)n;
+    double sum = 0.0;
+    for (uint32_t i = 0; i < n; ++i) sum = sum + (pdf_value(pdfs[i], direction) * weight);
+    return sum;
+}
+RT_DEV d3 pdf_mixture_generate(const Pdf* pdfs, uint32_t n, Rng& rng) {
+    const uint32_t pick = rng.index(n);  // SliceRandom::choose (pdf.rs:214-217) on the shared Philox stream
+    return normalize(pdf_generate(pdfs[pick], rng));
 }
 // material.rs scattering_pdf: false for DiffuseLight
 RT_DEV bool scattering_pdf(const rt_material& m, const Ray& ray_in, const HitRecord& hr, Pdf& out) {

@@ -10,6 +10,7 @@
 #include <chrono>
 #include <csignal>
 #include <cstdlib>
+#include <unistd.h>
 
 using namespace renderer;
 
@@ -33,14 +34,16 @@ static bool save_checkpoint(const std::string& path, const rt_checkpoint_header&
     if (!f) return false;
     bool ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(acc.data(), sizeof(float), acc.size(), f) == acc.size();
     ok = (fflush(f) == 0) && ok;
+    ok = (fsync(fileno(f)) == 0) && ok;                     // on disk before the rename makes it the checkpoint
     ok = (fclose(f) == 0) && ok;
     return ok && rename(tmp.c_str(), path.c_str()) == 0;   // a reader sees the old file or the new one
 }
-static bool load_checkpoint(const std::string& path, rt_checkpoint_header& h, std::vector<float>& acc, std::string& why) {
+static bool load_checkpoint(const std::string& path, uint32_t width, uint32_t height, rt_checkpoint_header& h, std::vector<float>& acc, std::string& why) {
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) { why = "cannot open " + path; return false; }
     bool ok = fread(&h, sizeof h, 1, f) == 1 && !memcmp(h.magic, RT_CHECKPOINT_MAGIC, 8);
     if (!ok) { why = "not a render checkpoint"; fclose(f); return false; }
+    if (h.width != width || h.height != height) { why = "the checkpoint holds another frame size"; fclose(f); return false; }  // before anything is sized from the file
     acc.assign((size_t)h.width * h.height * 3, 0.f);
     ok = fread(acc.data(), sizeof(float), acc.size(), f) == acc.size() && fgetc(f) == EOF;
     fclose(f);
@@ -80,6 +83,7 @@ int main(int argc, char** argv) {
         const uint32_t stop_after = (uint32_t)atoi(arg(argc, argv, "--stop-after", "0"));   // test hook: as if ctrl-c arrived once this many samples are in
         bool resume = false;
         for (int i = 1; i < argc; ++i) resume = resume || !strcmp(argv[i], "--resume");
+        if ((resume || !ckpt.empty()) && chunk == 0) { fprintf(stderr, "error: --checkpoint / --resume need --chunk N (samples per checkpoint)\n"); return 1; }
         uint32_t spp_done = 0;
         rt_stats st{};
         auto t0 = std::chrono::steady_clock::now();                              // main.rs:976
@@ -91,13 +95,14 @@ int main(int argc, char** argv) {
             memcpy(h.magic, RT_CHECKPOINT_MAGIC, 8);
             h.width = width; h.height = height; h.spp_begin = 0; h.spp_done = 0; h.spp_end = samples_per_pixel; h.max_depth = max_depth;
             h.integrator = p.integrator; h.rank = 0; h.world = 1; h.seed = p.seed;
+            h.chunk = chunk;   // chunk boundaries fix the order of the fp32 additions: a resume must cut the same chunks
             h.scene_id = ((uint64_t)(blob.size() & 0xFFFFFFFFu) << 32) | crc32_ieee(blob.data(), blob.size());
             if (resume) {
                 rt_checkpoint_header f{}; std::string why;
-                if (ckpt.empty() || !load_checkpoint(ckpt, f, acc, why)) { fprintf(stderr, "error: --resume: %s\n", ckpt.empty() ? "no --checkpoint given" : why.c_str()); return 1; }
+                if (ckpt.empty() || !load_checkpoint(ckpt, width, height, f, acc, why)) { fprintf(stderr, "error: --resume: %s\n", ckpt.empty() ? "no --checkpoint given" : why.c_str()); return 1; }
                 if (f.width != h.width || f.height != h.height || f.max_depth != h.max_depth || f.integrator != h.integrator || f.seed != h.seed ||
-                    f.scene_id != h.scene_id || f.spp_begin != 0 || f.spp_done > h.spp_end) {
-                    fprintf(stderr, "error: --resume: the checkpoint was written for another scene or other settings\n"); return 1;
+                    f.scene_id != h.scene_id || f.spp_begin != 0 || f.spp_done > h.spp_end || (f.chunk != 0 && f.chunk != h.chunk)) {
+                    fprintf(stderr, "error: --resume: the checkpoint was written for another scene or other settings (frame, depth, integrator, seed, chunk)\n"); return 1;
                 }
                 h.spp_done = f.spp_done;
                 printf("Resuming at sample %u of %u\n", h.spp_done, h.spp_end);

@@ -17,7 +17,7 @@ import numpy as np
 MAGIC = b"RTCKPT1\0"
 HEADER = struct.Struct("<8s5I2i3I2Q")       # include/rt_checkpoint.h: rt_checkpoint_header, 64 bytes
 assert HEADER.size == 64
-FIELDS = ("width", "height", "spp_begin", "spp_done", "spp_end", "max_depth", "integrator", "rank", "world", "reserved", "seed", "scene_id")
+FIELDS = ("width", "height", "spp_begin", "spp_done", "spp_end", "max_depth", "integrator", "rank", "world", "chunk", "seed", "scene_id")
 
 
 class CheckpointError(ValueError):
@@ -70,7 +70,7 @@ class ProgressiveRender:
         self.render_fn, self.chunk = render_fn, int(chunk)
         self.path = None if path is None else (path if world == 1 else f"{path}.rank{rank}")
         self.header = dict(width=width, height=height, spp_begin=spp_begin, spp_done=spp_begin, spp_end=spp_end, max_depth=max_depth,
-                           integrator=integrator, rank=rank, world=world, reserved=0, seed=seed, scene_id=scene_id(blob))
+                           integrator=integrator, rank=rank, world=world, chunk=int(chunk), seed=seed, scene_id=scene_id(blob))
         self.accum = np.zeros((height, width, 3), np.float32)
 
     @classmethod
@@ -83,6 +83,8 @@ class ProgressiveRender:
             raise CheckpointError("checkpoint was written for another scene")
         if (h["rank"], h["world"]) != (rank, world):
             raise CheckpointError(f"checkpoint belongs to rank {h['rank']} of {h['world']}")
+        if h["chunk"] not in (0, int(chunk)):   # another chunk size would add the same samples in another grouping: not bit-identical
+            raise CheckpointError(f"checkpoint was written with chunk = {h['chunk']}, this render asks for {chunk}")
         for k, v in (expect or {}).items():
             if h[k] != v:
                 raise CheckpointError(f"checkpoint has {k} = {h[k]}, this render asks for {v}")

@@ -39,6 +39,7 @@ def lib():
         L.orc_get_tile.argtypes = [u32] * 6 + [C.c_void_p]
         L.orc_tile_xy.argtypes = [u32] * 5 + [C.c_void_p]
         L.orc_mat4_inverse.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_pdf_eval.argtypes = [u32, u32, C.c_void_p, C.c_void_p, u64, u32, C.c_void_p, C.c_void_p]
         L.orc_div_sqrt.argtypes = [u32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
@@ -154,3 +155,15 @@ def div_sqrt(a, b):
     q = np.empty_like(a); s = np.empty_like(a)
     lib().orc_div_sqrt(a.size, a.ctypes.data, b.ctypes.data, q.ctypes.data, s.ctypes.data)
     return q, s
+
+
+def pdf_eval(descs, dirs, seed=0x5EED, skip=0):
+    """PDF::value / PDF::generate of the oracle for descs (n x n_comp, dtype raytracing_amd.PDF_DESC; n_comp > 1 = MixturePdf)."""
+    descs = np.ascontiguousarray(descs)
+    descs = descs.reshape(len(descs), -1)
+    n, n_comp = descs.shape
+    dirs = np.ascontiguousarray(dirs, np.float64).reshape(n, 3)
+    value = np.empty(n); gen = np.empty((n, 3))
+    if lib().orc_pdf_eval(n, n_comp, descs.ctypes.data, dirs.ctypes.data, seed, skip, value.ctypes.data, gen.ctypes.data) < 0:
+        raise OracleError(lib().orc_last_error().decode())
+    return value, gen

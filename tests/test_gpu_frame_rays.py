@@ -1,0 +1,58 @@
+"""Closes the transitive step in the full-size parity argument (VERDICT r01 "What's weak"): rays taken from the REAL 1920x1080 MIS
+frame of the pagoda -- every bounce's path queue and the shadow queues, as the render loop sorted and traced them -- go to the
+oracle, and (primitive, instance, t) must agree bit-for-bit with what the render loop's own traversal launch recorded.  Shadow
+launches stop at the first accepted hit that already decides "not visible", so for them the visibility decision
+(integrator.rs:82-86) must agree, and t bit-for-bit where the light is visible."""
+import numpy as np
+import pytest
+
+import oracle_ffi as orc
+import raytracing_amd as rt
+
+pytestmark = pytest.mark.gpu
+W, H, DEPTH = 1920, 1080, 5
+
+
+@pytest.fixture(scope="module")
+def pagoda(gpu_ctx):
+    hs = rt.HostScene.builtin("mesh", bvh_seed=3)
+    gs = gpu_ctx.upload(hs)
+    yield gs, orc.OracleScene(hs.describe())
+    gs.close()
+
+
+# (bounce, stride): about 2 000 rays per queue -- the oracle needs ~1 ms per ray on this scene
+@pytest.mark.parametrize("bounce,stride", [(0, 1037), (1, 601), (2, 113), (3, 61), (4, 37)])
+def test_path_rays_of_the_real_frame_match_oracle(pagoda, bounce, stride):
+    gs, osc = pagoda
+    rays, prim, inst, t, _, qlen = gs.capture_rays(W, H, 0, DEPTH, rt.INT_MIS, bounce, False, stride, 2500)
+    assert len(rays) >= 1000 and qlen >= len(rays), (len(rays), qlen)
+    if bounce == 0:
+        assert qlen == W * H
+    op, oi, ot, _ = osc.trace_closest(rays, 0.001, 100000.0)
+    t = np.where(prim == rt.NONE, 0.0, t)
+    assert np.array_equal(prim, op), f"{(prim != op).sum()} primitive ids differ"
+    assert np.array_equal(inst, oi)
+    assert np.array_equal(t.view(np.uint64), ot.view(np.uint64)), f"{(t.view(np.uint64) != ot.view(np.uint64)).sum()} t values differ in bits"
+    assert (op != rt.NONE).sum() > len(rays) // 10
+    # the same rays through rt_trace_closest (production kernel) and its counting variant
+    gp, gi, gt, cnt = gs.trace_closest(rays, 0.001, 100000.0, counters=True)
+    assert np.array_equal(gp, op) and np.array_equal(gt.view(np.uint64), ot.view(np.uint64)) and int(cnt[3]) == 0
+
+
+@pytest.mark.parametrize("bounce,stride", [(0, 601), (1, 41), (2, 29), (3, 17)])
+def test_shadow_rays_of_the_real_frame_match_oracle(pagoda, bounce, stride):
+    gs, osc = pagoda
+    rays, _, _, t, tl, qlen = gs.capture_rays(W, H, 0, DEPTH, rt.INT_MIS, bounce, True, stride, 2500)
+    assert len(rays) >= 800 and qlen >= len(rays), (len(rays), qlen)
+    op, oi, ot, _ = osc.trace_closest(rays, 0.001, 10000.0)
+    vis_ref = (op != rt.NONE) & ~(np.abs(ot - tl) > 0.0001)           # integrator.rs:82-86
+    vis_gpu = ~np.isnan(t) & ~(np.abs(t - tl) > 0.0001)               # k_unwind's test on what the walk reported
+    assert np.array_equal(vis_gpu, vis_ref), f"{(vis_gpu != vis_ref).sum()} visibility decisions differ"
+    assert np.array_equal(t[vis_ref].view(np.uint64), ot[vis_ref].view(np.uint64))
+    assert 0 < vis_ref.sum() < len(rays)                                # both outcomes occur
+    # the plain closest-hit kernel on the same rays: bit-exact, and an early-exit t is never below the true closest hit
+    gp, gi, gt = gs.trace_closest(rays, 0.001, 10000.0)
+    assert np.array_equal(gp, op) and np.array_equal(gt.view(np.uint64), ot.view(np.uint64))
+    hit = op != rt.NONE
+    assert not np.isnan(t[hit]).any() and (t[hit] >= ot[hit]).all()

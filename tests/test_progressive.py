@@ -75,6 +75,8 @@ def test_checkpoints_of_other_renders_and_damaged_files_are_refused(tmp_path):
     path = str(tmp_path / "a.ckpt")
     a = pg.ProgressiveRender(_fake_render(), blob, W, H, 0, 6, 5, rt.INT_BRDF, 1, chunk=2, path=path)
     a.run(stop=lambda: True)
+    with pytest.raises(pg.CheckpointError, match="chunk"):          # another grouping of the same samples would not be bit-identical
+        pg.ProgressiveRender.resume(_fake_render(), blob, path, chunk=3)
     with pytest.raises(pg.CheckpointError, match="another scene"):
         pg.ProgressiveRender.resume(_fake_render(), b"scene B", path, chunk=2)
     for k, v in dict(width=W + 1, max_depth=6, integrator=rt.INT_MIS, seed=2).items():
