@@ -169,6 +169,9 @@ typedef struct rt_render_params {
 } rt_render_params;
 #define RT_RENDER_COUNT_TESTS 1u /* also count box/primitive tests (slower kernel variant) */
 #define RT_RENDER_NO_SORT 2u     /* do not sort the ray queues by coherence key (octant | origin cell | direction bin); debug / A-B */
+#define RT_RENDER_LANE_WALK 8u   /* A-B: trace secondary and shadow rays with the per-lane walk (k_walk: own cursor and vector loads per lane, finished
+                                  * lanes take the next ray) in scenes that qualify (a pruned space, no instances); same frame, measured slower than the
+                                  * default wave-coherent walk */
 #define RT_RENDER_ONE_LANE 4u    /* run the passes of a call one after the other instead of two at a time (A-B; same frame) */
 
 typedef struct rt_stats {
@@ -191,6 +194,10 @@ typedef struct rt_stats {
     uint64_t shadow_rays;            /* the part of `rays` that were shadow rays */
     uint32_t samples_per_pass;       /* pass size the call used (a pure function of the parameters when samples_per_pass == 0) */
     uint32_t lanes;                  /* render lanes the call used (1 or 2) */
+    uint64_t walk_run_steps;         /* per-lane walk (k_walk): records visited, summed over rays (one 64-byte fetch each) */
+    uint64_t walk_tri_steps;         /* ... triangle-leaf visits (144 bytes each) */
+    uint64_t walk_slow_steps;        /* ... visits that needed f64 arithmetic (exact box / triangle / sphere tests) */
+    uint64_t walk_iterations;        /* ... block executions summed over waves (each runs ONE of fetch / record / triangle-leaf / f64 for its waiting lanes) */
 } rt_stats;
 
 /* number of visible HIP devices (>= 0) or negative error */

@@ -122,6 +122,37 @@ def test_two_render_lanes_give_the_frame_of_one(gpu_ctx, name, integ):
     gs.close()
 
 
+@pytest.mark.parametrize("name,integ,w,h", [("mesh", rt.INT_MIS, 480, 270), ("mesh", rt.INT_BRDF, 320, 180), ("random", rt.INT_MIS, 200, 112)])
+def test_per_lane_walk_gives_the_frame_of_the_wave_walk(gpu_ctx, name, integ, w, h):
+    # RT_RENDER_LANE_WALK traces secondary and shadow rays with k_walk (per-lane cursors, vector loads, ray replacement): the same
+    # records in the same order with the same filters and exact tests, so the accumulators are bit-identical to k_trace's
+    hs, _ = _pair(name)
+    gs = gpu_ctx.upload(hs)
+    a, sa = gs.render_host(w, h, 0, 6, 5, integ, seed=5)
+    b, sb = gs.render_host(w, h, 0, 6, 5, integ, seed=5, flags=rt.RENDER_LANE_WALK)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert sa.rays == sb.rays and sb.walk_run_steps > 0 and sa.walk_run_steps == 0
+    gs.close()
+
+
+def test_converged_pagoda_mis_independent_seeds(gpu_ctx):
+    # the second north-star correctness test on the scene it names: pagoda, MIS (integrator.rs:31-171), at a reduced frame the oracle
+    # renders in seconds.  Stated tolerance, as below: rRMSE(gpu, oracle) <= 1.6 * rRMSE(oracle seed B, oracle seed C) + 0.01.
+    hs, osc = _pair("mesh")
+    gs = gpu_ctx.upload(hs)
+    w, h, spp = 64, 36, 48
+    g, _ = gs.render_host(w, h, 0, spp, 5, rt.INT_MIS, seed=1001)
+    o1, _ = osc.render(w, h, 0, spp, 5, rt.INT_MIS, seed=2002, nthreads=16)
+    o2, _ = osc.render(w, h, 0, spp, 5, rt.INT_MIS, seed=3003, nthreads=16)
+
+    def rrmse(a, b):
+        a = a / spp; b = b / spp
+        return float(np.sqrt(np.mean(((a - b) / (0.5 * (a + b) + 1e-2)) ** 2)))
+    assert rrmse(g, o1) <= 1.6 * rrmse(o1, o2) + 0.01, (rrmse(g, o1), rrmse(o1, o2))
+    assert abs(g.mean() - o1.mean()) / o1.mean() < 0.03
+    gs.close()
+
+
 def test_converged_images_independent_seeds(gpu_ctx):
     # north-star "converged images": GPU (seed A) vs oracle (seed B) are independent estimates of the same
     # image; per-pixel relative RMSE over the frame must be at the Monte Carlo noise level.
