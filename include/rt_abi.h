@@ -206,7 +206,7 @@ int rt_device_count(void);
  * to void*, e.g. torch.cuda.current_stream().cuda_stream) or NULL for a library-owned stream.
  * Also takes the device address of this GPU's fixed scratch array (rt_trace_closest_device_noalloc). */
 int rt_context_create(int device, void* stream, rt_context** out);
-int rt_context_destroy(rt_context* ctx);
+int rt_context_destroy(rt_context* ctx); /* RT_ERR_BAD_ARG while scenes uploaded through it are alive: destroy those first */
 int rt_context_synchronize(rt_context* ctx);
 
 /* Validates and copies the flattened blob to the device (caller keeps `blob`). */
@@ -243,7 +243,8 @@ int rt_prune_info_host(const void* blob, uint64_t nbytes, double* info, uint32_t
 int rt_trace_closest(rt_scene* scene, uint32_t n, const double* rays, double t_min, double t_max,
                      uint32_t* prim_id, uint32_t* inst_id, double* t, uint64_t* counters);
 /* Same, everything already resident: rays_dev n x 7 doubles, outputs device arrays; asynchronous on
- * the context stream.  This is the entry bench.py times for the traversal kernel alone. */
+ * the context stream.  Device conventions differ from the host variant: prim_id_dev holds the INDEX into the blob's prims
+ * table (RT_NONE on a miss), and t_dev is NaN (not 0) on a miss. */
 int rt_trace_closest_device(rt_scene* scene, uint32_t n, const double* rays_dev, double t_min, double t_max,
                             uint32_t* prim_id_dev, double* t_dev);
 /* rt_trace_closest_device for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses

@@ -6,6 +6,7 @@ Thin Python face over the two C libraries:
 Nothing here computes: numpy only carries buffers.  Missing librt_hip.so raises.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -128,6 +129,19 @@ class Context:
         _hip_check(L.rt_context_create(device, C.c_void_p(stream) if stream else None, C.byref(h)))
         self._h = h
         self.device = device
+        self._scenes = []   # weak references to live GpuScene objects: closed before the context
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def upload(self, scene):
         blob = scene.blob() if isinstance(scene, HostScene) else scene
@@ -160,7 +174,12 @@ class Context:
 
     def close(self):
         if self._h:
-            _ffi.hip().rt_context_destroy(self._h)
+            for ref in list(self._scenes):   # a scene keeps a pointer to its context: release the scenes first
+                sc = ref()
+                if sc is not None:
+                    sc.close()
+            self._scenes.clear()
+            _hip_check(_ffi.hip().rt_context_destroy(self._h))
             self._h = None
 
 
@@ -171,7 +190,20 @@ class GpuScene:
         h = C.c_void_p()
         _hip_check(_ffi.hip().rt_scene_upload(ctx._h, blob, len(blob), C.byref(h)))
         self._h = h
-        self.ctx = ctx
+        self.ctx = ctx   # keeps the context alive as long as the scene
+        ctx._scenes.append(weakref.ref(self))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):   # a dropped scene would otherwise hold its path buffers (up to two thirds of HBM)
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def trace_closest(self, rays, t_min, t_max, counters=False):
         rays = np.ascontiguousarray(rays, np.float64).reshape(-1, 7)

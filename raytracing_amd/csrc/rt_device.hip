@@ -1691,6 +1691,7 @@ struct rt_context {
     hipStream_t stream;
     bool own_stream;
     unsigned char* scratch;  // this device's copy of `scratch` (device address)
+    int live_scenes = 0;     // rt_scene handles that still point at this context (rt_context_destroy refuses while > 0)
 };
 
 struct Workspace {
@@ -2272,6 +2273,7 @@ int rt_context_create(int device, void* stream, rt_context** out) {
 }
 int rt_context_destroy(rt_context* ctx) {
     if (!ctx) return RT_OK;
+    if (ctx->live_scenes > 0) return fail(RT_ERR_BAD_ARG, "rt_context_destroy: " + std::to_string(ctx->live_scenes) + " scene(s) of this context are still alive (destroy them first)");
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -2625,6 +2627,7 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     rt_scene* sc = new (std::nothrow) rt_scene();
     if (!sc) return fail(RT_ERR_OOM, "host allocation failed");
     sc->ctx = ctx; sc->hdr = h;
+    ctx->live_scenes += 1;
     sc->host_prims.assign(prims, prims + h.n_prims);
     sc->has_instances = P.has_instances; sc->reg_ray = P.reg_ray;
 #ifndef RT_TRACE_DIAG   /* the diagnostic build reports k_trace's own step counts */
@@ -2671,6 +2674,7 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
         if (sc->d_cert_planes) (void)hipFree(sc->d_cert_planes);
         if (sc->d_cert_plane_off) (void)hipFree(sc->d_cert_plane_off);
         if (sc->d_cert_plane_leaf) (void)hipFree(sc->d_cert_plane_leaf);
+        ctx->live_scenes -= 1;
         delete sc;
         return fail(e == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, hipGetErrorString(e));
     }
@@ -2736,6 +2740,7 @@ int rt_scene_destroy(rt_scene* sc) {
     if (sc->d_cert_planes) (void)hipFree(sc->d_cert_planes);
     if (sc->d_cert_plane_off) (void)hipFree(sc->d_cert_plane_off);
     if (sc->d_cert_plane_leaf) (void)hipFree(sc->d_cert_plane_leaf);
+    sc->ctx->live_scenes -= 1;
     delete sc;
     return RT_OK;
 }
@@ -2836,6 +2841,7 @@ static int check_params(const rt_render_params* p) {
 
 int rt_accum_zero(rt_context* ctx, float* accum_dev, uint32_t width, uint32_t height) {
     if (!ctx || !accum_dev) return fail(RT_ERR_BAD_ARG, "rt_accum_zero: null argument");
+    if ((uint64_t)width * height > (1ull << 28)) return fail(RT_ERR_BAD_ARG, "rt_accum_zero: frame too large");
     HIP_OK(hipSetDevice(ctx->device));
     HIP_OK(hipMemsetAsync(accum_dev, 0, (size_t)width * height * 3 * sizeof(float), ctx->stream));
     return RT_OK;
@@ -3033,6 +3039,7 @@ int rt_render_host(rt_scene* sc, const rt_render_params* p, float* accum_host, r
 
 int rt_resolve(rt_context* ctx, const float* accum_dev, uint32_t width, uint32_t height, uint32_t spp, int tonemap, float* out_dev) {
     if (!ctx || !accum_dev || !out_dev || spp == 0) return fail(RT_ERR_BAD_ARG, "rt_resolve: bad argument");
+    if ((uint64_t)width * height > (1ull << 28)) return fail(RT_ERR_BAD_ARG, "rt_resolve: frame too large");
     HIP_OK(hipSetDevice(ctx->device));
     const uint32_t n3 = width * height * 3;
     hipLaunchKernelGGL(k_resolve, grid_for(n3), dim3(256), 0, ctx->stream, accum_dev, n3, 0.f, spp, tonemap, out_dev);
@@ -3042,6 +3049,7 @@ int rt_resolve(rt_context* ctx, const float* accum_dev, uint32_t width, uint32_t
 
 int rt_resolve_host(const float* accum_host, uint32_t width, uint32_t height, uint32_t spp, int tonemap, float* out_host) {
     if (!accum_host || !out_host || spp == 0) return fail(RT_ERR_BAD_ARG, "rt_resolve_host: bad argument");
+    if ((uint64_t)width * height > (1ull << 28)) return fail(RT_ERR_BAD_ARG, "rt_resolve_host: frame too large");
     const size_t bytes = (size_t)width * height * 3 * sizeof(float);
     float *a = nullptr, *o = nullptr;
     HIP_OK(hipMalloc((void**)&a, bytes));

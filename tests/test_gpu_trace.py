@@ -197,3 +197,20 @@ def test_gpu_matches_committed_golden_vectors(gpu_ctx):
             ok = (np.abs(got - ref) <= 1e-9 * (np.abs(ref) + 1e-3)) | (np.isnan(got) & np.isnan(ref))
             assert ok.all(axis=1).mean() >= 0.97, (name, integ)
         gs.close()
+
+
+def test_context_outlives_its_scenes():
+    # rt_scene keeps a pointer to its rt_context: the C ABI refuses to destroy a context with live scenes, and the Python wrapper
+    # closes the scenes first
+    import ctypes as C
+    from raytracing_amd import _ffi
+    ctx = rt.Context(0)
+    gs = ctx.upload(rt.HostScene.builtin("simple_triangle"))
+    assert _ffi.hip().rt_context_destroy(ctx._h) == -1 and b"still alive" in _ffi.hip().rt_last_error()
+    rays = np.array([[0.0, 0.5, -2.0, 0.0, 0.0, 1.0, 0.0]])
+    assert gs.trace_closest(rays, 0.001, 1e5)[0][0] != rt.NONE          # both handles still work
+    ctx.close()                                                          # closes gs, then the context
+    assert gs._h is None and ctx._h is None
+    with rt.Context(0) as c2, c2.upload(rt.HostScene.builtin("simple_triangle")) as g2:
+        assert g2.trace_closest(rays, 0.001, 1e5)[0][0] != rt.NONE
+    assert c2._h is None
