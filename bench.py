@@ -3,9 +3,11 @@
 (`MultipleImportanceSampleIntegrator`, integrator.rs:31-171 -- the one the reference's main() selects), depth 5
 (main.rs:944), 1000 spp = configs[2], which fits one GPU.
 
-A "step" is one rt_render call (ray-gen -> [traverse -> shade -> traverse shadow rays] x depth -> unwind -> accumulate)
-over --spp-per-step samples of every pixel; the default 50 makes the driver's `--steps 20` exactly the 1000-spp frame
-(two render lanes of 25-spp passes per call).  Inputs (the flattened scene) are resident in HBM before the timed region;
+A "step" is one render call (ray-gen -> [traverse -> shade -> traverse shadow rays] x depth -> unwind -> accumulate)
+over --spp-per-step samples of every pixel; the default 50 makes the driver's `--steps 20` exactly the 1000-spp frame.
+Steps are queued with rt_render_begin and waited for with rt_render_end, two in flight (one 50-spp pass each, on the scene's
+two lanes): the thin deep bounces of one step overlap the next step's kernels; --sync-steps runs blocking rt_render calls
+(two lanes of 25-spp passes inside each call) instead.  Inputs (the flattened scene) are resident in HBM before the timed region;
 accumulators stay on the device.  N ranks: `--scaling weak` (default) gives every rank its own disjoint range of
 steps x spp_per_step absolute sample indices; `--scaling strong` splits each step's samples across the ranks
 (distributed.spp_range).  One broadcast of the scene bytes before, one all-reduce of the fp32 sums inside the timed region.
@@ -56,6 +58,7 @@ def parse_args(argv=None):
     ap.add_argument("--spp-per-step", type=int, default=50)       # x the driver's 20 steps = the 1000 spp of the metric
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
     ap.add_argument("--one-lane", action="store_true")            # A/B: the passes of a call one after the other
+    ap.add_argument("--sync-steps", action="store_true")          # A/B: every step a blocking rt_render (two lanes inside the call) instead of two steps in flight
     ap.add_argument("--bvh-seed", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -104,8 +107,16 @@ class HipRenderer:
         self.gs = self.ctx.upload(blob)
         self.flags = rt.RENDER_ONE_LANE if args.one_lane else 0
 
-    def render(self, accum, b, e, flags=0):
-        return self.gs.render(accum.data_ptr(), self.W, self.H, b, e, self.depth, self.integrator, seed=0x5EED, flags=self.flags | flags).as_dict()
+    def render(self, accum, b, e, flags=0, samples_per_pass=0):
+        return self.gs.render(accum.data_ptr(), self.W, self.H, b, e, self.depth, self.integrator, seed=0x5EED, samples_per_pass=samples_per_pass,
+                              flags=self.flags | flags).as_dict()
+
+    # rt_render_begin / rt_render_end: the call is queued on one of the scene's two lanes; two calls may be in flight
+    def begin(self, accum, b, e):
+        return self.gs.render_begin(accum.data_ptr(), self.W, self.H, b, e, self.depth, self.integrator, seed=0x5EED, flags=self.flags)
+
+    def end(self, job):
+        return self.gs.render_end(job).as_dict()
 
     def close(self):
         self.gs.close(); self.ctx.close()
@@ -184,22 +195,37 @@ def main():
             return b, b + spp_step
         return rtd.spp_range(rank, world, spp_step, i * spp_step)   # strong: step i = samples [i*spp_step, (i+1)*spp_step) split over the ranks
 
+    pipelined = hasattr(R, "begin") and not args.sync_steps and not args.one_lane
+
+    def run_steps(first, count):
+        """`count` steps; pipelined: steps are queued two at a time (rt_render_begin x2, then rt_render_end x2), one 50-spp pass each
+        on the scene's two lanes, so the thin deep bounces of one step overlap the other step's.  Begun TOGETHER on purpose: two steps
+        in the same phase measured 6 % faster than a staggered pair (a thin launch queued behind the other step's full-machine
+        launch waits for it).  Every step still adds its sums after the step before it."""
+        out, pending = [], []
+        for i in range(first, first + count):
+            b, e = step_range(i)
+            if e <= b:
+                continue
+            if pipelined:
+                pending.append(R.begin(accum, b, e))
+                if len(pending) == 2:
+                    out += [R.end(pending.pop(0)), R.end(pending.pop(0))]
+            else:
+                out.append(R.render(accum, b, e))
+        while pending:
+            out.append(R.end(pending.pop(0)))
+        return out
+
     sync()
-    for i in range(args.warmup):
-        b, e = step_range(i)
-        if e > b:
-            R.render(accum, b, e)
+    run_steps(0, args.warmup)
     accum.zero_()
     sync()
     if world > 1:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
-    stats = []
-    for i in range(args.steps):
-        b, e = step_range(args.warmup + i)
-        if e > b:
-            stats.append(R.render(accum, b, e))
+    stats = run_steps(args.warmup, args.steps)
     rtd.allreduce_accum(accum)
     sync()
     if world > 1:
@@ -226,6 +252,7 @@ def main():
             "data": "synthetic (reference pagoda OBJ asset, Lambertian 0.5 albedo; Philox-seeded camera samples)",
             "config": {"workload": args.workload, "scene": scene, "width": W, "height": H, "integrator": INTEGRATOR_NAMES[integrator],
                        "max_depth": depth, "spp_per_step": spp_step, "render_lanes": 1 if args.one_lane else 2, "spp_total": spp_total,
+                       "steps_in_flight": 2 if pipelined else 1,
                        "sharding": f"spp-range x{world}" if world > 1 else "none", "bvh_seed": args.bvh_seed},
             "paths_per_s": paths_all / t_max, "rays": rays_all, "paths": paths_all,
             "accum_checksum": float(accum.double().sum()),
@@ -249,7 +276,7 @@ def report_kernels(args, R, accum, stats, step_range, rays, spp_step):
     machine) and a 1-spp pass of the counting kernel (reference-order test counts: what the traversal replaces)."""
     rt = R.rt
     b, e = step_range(args.warmup)
-    alone = R.render(accum, b, e, flags=rt.RENDER_ONE_LANE)
+    alone = R.render(accum, b, e, flags=rt.RENDER_ONE_LANE, samples_per_pass=stats[0]["samples_per_pass"] if stats else 0)
     counted = R.render(accum, b, b + 1, flags=rt.RENDER_COUNT_TESTS)
     r1 = max(counted["rays"], 1)
     n_box, n_tri, n_sph = counted["box_tests"] / r1, counted["tri_tests"] / r1, counted["sphere_tests"] / r1

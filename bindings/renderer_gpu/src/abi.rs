@@ -240,6 +240,7 @@ pub struct rt_checkpoint_header {
 
 pub enum rt_context {}
 pub enum rt_scene {}
+pub enum rt_job {}
 
 extern "C" {
     pub fn rt_device_count() -> c_int;
@@ -256,6 +257,8 @@ extern "C" {
     pub fn rt_trace_closest_device_noalloc(scene: *mut rt_scene, n: u32, rays_dev: *const f64, t_min: f64, t_max: f64, prim_id_dev: *mut u32, t_dev: *mut f64) -> c_int;
     pub fn rt_primary_rays(scene: *mut rt_scene, width: u32, height: u32, sample: u32, seed: u64, rays: *mut f64) -> c_int;
     pub fn rt_render(scene: *mut rt_scene, params: *const rt_render_params, accum_dev: *mut f32, stats: *mut rt_stats) -> c_int;
+    pub fn rt_render_begin(scene: *mut rt_scene, params: *const rt_render_params, accum_dev: *mut f32, job: *mut *mut rt_job) -> c_int;
+    pub fn rt_render_end(job: *mut rt_job, stats: *mut rt_stats) -> c_int;
     pub fn rt_capture_rays(scene: *mut rt_scene, params: *const rt_render_params, bounce: u32, shadow: c_int, stride: u32, max_n: u32, n_out: *mut u32, queue_len: *mut u32,
                            rays: *mut f64, prim_id: *mut u32, inst_id: *mut u32, t: *mut f64, t_light: *mut f64) -> c_int;
     pub fn rt_accum_zero(ctx: *mut rt_context, accum_dev: *mut f32, width: u32, height: u32) -> c_int;

@@ -267,6 +267,16 @@ int rt_primary_rays(rt_scene* scene, uint32_t width, uint32_t height, uint32_t s
  * all-reduce(sum) their accumulators before rt_resolve.  Synchronous: returns when accum is final. */
 int rt_render(rt_scene* scene, const rt_render_params* params, float* accum_dev, rt_stats* stats);
 int rt_accum_zero(rt_context* ctx, float* accum_dev, uint32_t width, uint32_t height);
+/* rt_render split in two, so that consecutive calls overlap on the GPU (the thin deep bounces of one call leave the machine part-idle;
+ * the next call's kernels fill it -- what the two lanes do INSIDE one rt_render, without halving the pass size).  rt_render_begin
+ * queues the call on one of the scene's two lanes (own stream, own path buffers, a host thread for the per-bounce readbacks) and
+ * returns; rt_render_end waits for it, fills stats and frees the job.  At most two jobs per scene are in flight: begin, begin,
+ * end(first), begin, ...  Jobs add their sums to the accumulator in the order they were begun (pass size = the default of rt_render
+ * without the "half the call" rule, or samples_per_pass), so a sequence of jobs gives one well-defined frame.  While jobs are in flight
+ * the scene accepts no other call.  RT_RENDER_COUNT_TESTS is not available here.  No counterpart in the reference. */
+typedef struct rt_job rt_job;
+int rt_render_begin(rt_scene* scene, const rt_render_params* params, float* accum_dev, rt_job** job);
+int rt_render_end(rt_job* job, rt_stats* stats);
 /* Host-memory convenience for callers without device allocations (the `desktop` app): allocates a
  * device accumulator internally, renders, copies the sums to host accum (width*height*3 fp32). */
 int rt_render_host(rt_scene* scene, const rt_render_params* params, float* accum_host, rt_stats* stats);

@@ -236,6 +236,18 @@ class GpuScene:
         _hip_check(_ffi.hip().rt_render(self._h, C.byref(p), C.c_void_p(accum_ptr), C.byref(st)))
         return st
 
+    def render_begin(self, accum_ptr, width, height, spp_begin, spp_end, max_depth, integrator, seed=0x5EED, samples_per_pass=0, flags=0):
+        """rt_render_begin: queues the call (at most two in flight per scene) and returns a job handle for render_end."""
+        p = self._params(width, height, spp_begin, spp_end, max_depth, integrator, seed, samples_per_pass, flags)
+        job = C.c_void_p()
+        _hip_check(_ffi.hip().rt_render_begin(self._h, C.byref(p), C.c_void_p(accum_ptr), C.byref(job)))
+        return job
+
+    def render_end(self, job):
+        st = Stats()
+        _hip_check(_ffi.hip().rt_render_end(job, C.byref(st)))
+        return st
+
     def capture_rays(self, width, height, sample, max_depth, integrator, bounce, shadow, stride, max_n, seed=0x5EED, flags=0):
         """Every stride-th ray of the render loop's queue at `bounce` (shadow rays if shadow) for one sample of every pixel, with the
         loop's own traversal result: (rays n x 7, prim, inst, t, t_light, queue length)."""

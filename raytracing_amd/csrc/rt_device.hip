@@ -1737,7 +1737,22 @@ struct rt_scene {
     Workspace ws2;                  // second render lane (rt_render runs two passes at a time, each on its own stream)
     hipStream_t stream2 = nullptr;
     uint64_t ws2_failed_cap = ~0ull;  // smallest second-lane size (paths) that could not be allocated
+    // rt_render_begin / rt_render_end: at most one job per lane in flight; jobs add to the accumulator in the order they were begun
+    struct rt_job* lane_job[2] = {nullptr, nullptr};
+    uint64_t job_seq = 0;               // jobs begun so far
+    hipEvent_t job_done[4] = {nullptr, nullptr, nullptr, nullptr};   // job k records job_done[k % 4] after its last accumulate
+    std::mutex job_mu; std::condition_variable job_cv; uint64_t jobs_recorded = 0;   // jobs whose done-event has been recorded (host side)
+    std::thread worker[2];              // one host thread per lane, started by the first rt_render_begin on that lane (a fresh thread per job costs HIP's per-thread set-up every time)
+    bool workers_quit = false;
 };
+
+struct rt_job {
+    rt_scene* sc = nullptr; rt_render_params p{}; float* accum = nullptr; int lane = 0; uint64_t seq = 0; uint32_t spass = 1;
+    bool started = false, finished = false;   // under rt_scene::job_mu
+    int rc = RT_OK; std::string err; rt_stats st{};
+};
+static bool scene_busy(rt_scene* sc) { return sc->lane_job[0] != nullptr || sc->lane_job[1] != nullptr; }
+#define RT_NOT_BUSY(sc, who) do { if (scene_busy(sc)) return fail(RT_ERR_BAD_ARG, who ": render jobs begun with rt_render_begin are still in flight on this scene (rt_render_end them first)"); } while (0)
 
 static void ws_free(Workspace& ws) {
     for (void* p : ws.allocs) (void)hipFree(p);
@@ -2722,9 +2737,18 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     return RT_OK;
 }
 
+int rt_render_end(rt_job* job, rt_stats* stats);
 int rt_scene_destroy(rt_scene* sc) {
     if (!sc) return RT_OK;
     (void)hipSetDevice(sc->ctx->device);
+    for (int k = 0; k < 2; ++k) {   // jobs nobody ended: in the order they were begun
+        rt_job* first = sc->lane_job[0] && (!sc->lane_job[1] || sc->lane_job[0]->seq < sc->lane_job[1]->seq) ? sc->lane_job[0] : sc->lane_job[1];
+        if (first) (void)rt_render_end(first, nullptr);
+    }
+    { std::lock_guard<std::mutex> lk(sc->job_mu); sc->workers_quit = true; }
+    sc->job_cv.notify_all();
+    for (auto& w : sc->worker) if (w.joinable()) w.join();
+    for (auto& e : sc->job_done) if (e) (void)hipEventDestroy(e);
     (void)hipStreamSynchronize(sc->ctx->stream);
     ws_free(sc->ws); ws_free(sc->ws2);
     if (sc->stream2) (void)hipStreamDestroy(sc->stream2);
@@ -2748,6 +2772,7 @@ int rt_scene_destroy(rt_scene* sc) {
 int rt_trace_closest_device(rt_scene* sc, uint32_t n, const double* rays_dev, double t_min, double t_max, uint32_t* prim_id_dev, double* t_dev) {
     if (!sc || (n && (!rays_dev || !prim_id_dev || !t_dev))) return fail(RT_ERR_BAD_ARG, "rt_trace_closest_device: null argument");
     if (n == 0) return RT_OK;
+    RT_NOT_BUSY(sc, "rt_trace_closest_device");
     HIP_OK(hipSetDevice(sc->ctx->device));
     int rc = ws_ensure(sc, n, sc->ws.depth > 0 ? sc->ws.depth : 1);
     if (rc != RT_OK) return rc;
@@ -2778,6 +2803,7 @@ int rt_trace_closest(rt_scene* sc, uint32_t n, const double* rays, double t_min,
                      uint64_t* counters) {
     if (!sc || (n && (!rays || !prim_id || !t))) return fail(RT_ERR_BAD_ARG, "rt_trace_closest: null argument");
     if (n == 0) { if (counters) for (int k = 0; k < 8; ++k) counters[k] = 0; return RT_OK; }
+    RT_NOT_BUSY(sc, "rt_trace_closest");
     HIP_OK(hipSetDevice(sc->ctx->device));
     int rc = ws_ensure(sc, n, sc->ws.depth > 0 ? sc->ws.depth : 1);
     if (rc != RT_OK) return rc;
@@ -2829,6 +2855,13 @@ int rt_primary_rays(rt_scene* sc, uint32_t width, uint32_t height, uint32_t samp
     return RT_OK;
 }
 
+// samples_per_pass == 0: a pure function of the parameters (see rt_render)
+static uint32_t default_pass_size(uint32_t npix, int32_t max_depth) {
+    const uint64_t by_paths = std::max<uint64_t>(1, (128ull << 20) / npix);
+    const uint64_t by_mem = std::max<uint64_t>(1, (80ull << 30) / ((uint64_t)npix * ((uint64_t)max_depth * REC_STRIDE * 8 + 320)));
+    return (uint32_t)std::min<uint64_t>(std::min(by_paths, by_mem), 256);
+}
+
 static int check_params(const rt_render_params* p) {
     if (!p) return fail(RT_ERR_BAD_ARG, "null params");
     if (p->width < 2 || p->height < 2) return fail(RT_ERR_BAD_ARG, "width/height must be >= 2 (u = (x+xi)/(width-1), main.rs:996)");
@@ -2851,6 +2884,7 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
     if (!sc || !accum_dev) return fail(RT_ERR_BAD_ARG, "rt_render: null argument");
     int rc = check_params(p);
     if (rc != RT_OK) return rc;
+    RT_NOT_BUSY(sc, "rt_render");
     HIP_OK(hipSetDevice(sc->ctx->device));
     const uint32_t npix = p->width * p->height;
     const uint32_t spp = p->spp_end - p->spp_begin;
@@ -2872,10 +2906,7 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
         // same passes to stay bit-identical.  Budget: 80 GiB of path state per lane (two lanes + scene fit the 288 GB), at most
         // 128M paths, at most half the call's samples so that both lanes have work.  If the buffers do not fit (a shared GPU),
         // the call fails with RT_ERR_OOM and the caller chooses samples_per_pass itself.
-        const uint64_t by_paths = std::max<uint64_t>(1, (128ull << 20) / npix);
-        const uint64_t by_mem = std::max<uint64_t>(1, (80ull << 30) / ((uint64_t)npix * ((uint64_t)p->max_depth * REC_STRIDE * 8 + 320)));
-        spass = (uint32_t)std::min<uint64_t>(std::min(by_paths, by_mem), 256);
-        spass = std::min(spass, (spp + 1u) / 2u);
+        spass = std::min(default_pass_size(npix, p->max_depth), (spp + 1u) / 2u);
     }
     spass = std::max(1u, std::min(spass, spp));
     if ((uint64_t)npix * spass > 0x7FFFFF00ull) return fail(RT_ERR_BAD_ARG, "samples_per_pass * pixels too large");
@@ -2986,12 +3017,153 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
     return rc;
 }
 
+// One job = one rt_render call on ONE lane (own stream, own path buffers, own host thread for the per-bounce readbacks).
+static void job_main(rt_job* J) {
+    rt_scene* sc = J->sc;
+    const rt_render_params& p = J->p;
+    auto body = [&]() -> int {
+        HIP_OK(hipSetDevice(sc->ctx->device));
+        Workspace& ws = J->lane == 0 ? sc->ws : sc->ws2;
+        hipStream_t st = J->lane == 0 ? sc->ctx->stream : sc->stream2;
+        const uint32_t npix = p.width * p.height, spp = p.spp_end - p.spp_begin;
+        EventTimer tm(st, true);
+        uint64_t launches = 0, shadow_rays = 0;
+        hipEvent_t e0, e1;
+        HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+        HIP_OK(hipEventRecord(e0, st));
+        HIP_OK(hipMemsetAsync(ws.stats, 0, 16 * sizeof(unsigned long long), st));
+        const bool sort_rays = (p.flags & RT_RENDER_NO_SORT) == 0 && sc->sortable;
+        bool waited = J->seq == 0;
+        for (uint32_t s0 = p.spp_begin; s0 < p.spp_end; s0 += J->spass) {
+            const uint32_t ns = std::min(J->spass, p.spp_end - s0);
+            int r = run_paths(sc, ws, st, npix * ns, false, p.width, p.height, s0, p.max_depth, p.integrator, p.seed, false, sort_rays, tm, launches, &shadow_rays, nullptr,
+                              (p.flags & RT_RENDER_LANE_WALK) != 0);
+            if (r != RT_OK) return r;
+            if (!waited) {   // the job begun before this one adds its sums first (fixed order of the fp32 additions)
+                std::unique_lock<std::mutex> lk(sc->job_mu);
+                sc->job_cv.wait(lk, [&] { return sc->jobs_recorded >= J->seq; });
+                lk.unlock();
+                HIP_OK(hipStreamWaitEvent(st, sc->job_done[(J->seq - 1) % 4], 0));
+                waited = true;
+            }
+            tm.begin(CAT_OTHER);
+            hipLaunchKernelGGL(k_accumulate, grid_for(npix), dim3(256), 0, st, ws.pb.radiance, ws.pb.info, ws.cap, npix, ns, J->accum);
+            tm.end();
+            launches += 1;
+        }
+        HIP_OK(hipEventRecord(sc->job_done[J->seq % 4], st));
+        { std::lock_guard<std::mutex> lk(sc->job_mu); sc->jobs_recorded = J->seq + 1; }
+        sc->job_cv.notify_all();
+        HIP_OK(hipEventRecord(e1, st));
+        unsigned long long st4[16] = {};
+        HIP_OK(hipMemcpyAsync(st4, ws.stats, sizeof st4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        HIP_OK(hipGetLastError());
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        double by_cat[CAT_N] = {0, 0, 0, 0}; uint64_t n_by_cat[CAT_N] = {0, 0, 0, 0};
+        tm.collect(by_cat, CAT_N, n_by_cat);
+        rt_stats& S = J->st;
+        S.rays = st4[0]; S.paths = (uint64_t)npix * spp; S.launches = launches; S.ms_total = ms;
+        S.ms_trace = by_cat[CAT_TRACE] + by_cat[CAT_SHADOW]; S.ms_shade = by_cat[CAT_SHADE]; S.ms_other = by_cat[CAT_OTHER];
+        S.trace_launches = n_by_cat[CAT_TRACE] + n_by_cat[CAT_SHADOW]; S.trace_wave_steps = st4[15];
+        S.ms_trace_shadow = by_cat[CAT_SHADOW]; S.trace_shadow_launches = n_by_cat[CAT_SHADOW]; S.shadow_rays = shadow_rays;
+        S.samples_per_pass = J->spass; S.lanes = 1;
+        S.walk_run_steps = st4[4]; S.walk_tri_steps = st4[5]; S.walk_slow_steps = st4[6]; S.walk_iterations = st4[7];
+        return RT_OK;
+    };
+    J->rc = body();
+    if (J->rc != RT_OK) {
+        J->err = g_err;
+        // the jobs behind this one must not wait for ever: count it as recorded (their sums are then meaningless, and their rt_render_end says why)
+        { std::lock_guard<std::mutex> lk(sc->job_mu); sc->jobs_recorded = std::max(sc->jobs_recorded, J->seq + 1); }
+        sc->job_cv.notify_all();
+    }
+}
+
+static void lane_worker(rt_scene* sc, int lane) {
+    for (;;) {
+        rt_job* J = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(sc->job_mu);
+            sc->job_cv.wait(lk, [&] { return sc->workers_quit || (sc->lane_job[lane] && !sc->lane_job[lane]->started); });
+            if (sc->workers_quit) return;
+            J = sc->lane_job[lane];
+            J->started = true;
+        }
+        job_main(J);
+        { std::lock_guard<std::mutex> lk(sc->job_mu); J->finished = true; }
+        sc->job_cv.notify_all();
+    }
+}
+
+int rt_render_begin(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_job** out) {
+    if (!sc || !accum_dev || !out) return fail(RT_ERR_BAD_ARG, "rt_render_begin: null argument");
+    int rc = check_params(p);
+    if (rc != RT_OK) return rc;
+    if (p->flags & RT_RENDER_COUNT_TESTS) return fail(RT_ERR_BAD_ARG, "rt_render_begin: the counting kernel runs through rt_render");
+    if (p->spp_end == p->spp_begin || p->max_depth == 0) return fail(RT_ERR_BAD_ARG, "rt_render_begin: empty sample range or depth 0 (nothing to render)");
+    const int lane = (int)(sc->job_seq % 2);
+    if (sc->lane_job[lane]) return fail(RT_ERR_BAD_ARG, "rt_render_begin: two jobs are in flight already (rt_render_end the older one first)");
+    HIP_OK(hipSetDevice(sc->ctx->device));
+    const uint32_t npix = p->width * p->height, spp = p->spp_end - p->spp_begin;
+    uint32_t spass = p->samples_per_pass ? p->samples_per_pass : default_pass_size(npix, p->max_depth);   // one lane per job: not halved
+    spass = std::max(1u, std::min(spass, spp));
+    if ((uint64_t)npix * spass > 0x7FFFFF00ull) return fail(RT_ERR_BAD_ARG, "samples_per_pass * pixels too large");
+    if (lane == 1 && !sc->stream2) HIP_OK(hipStreamCreateWithFlags(&sc->stream2, hipStreamNonBlocking));
+    for (auto& e : sc->job_done) if (!e) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    rc = ws_ensure(sc, lane == 0 ? sc->ws : sc->ws2, npix * spass, p->max_depth);
+    if (rc != RT_OK) return rc;
+    rt_job* J = new (std::nothrow) rt_job();
+    if (!J) return fail(RT_ERR_OOM, "rt_render_begin: host allocation failed");
+    J->sc = sc; J->p = *p; J->accum = accum_dev; J->lane = lane; J->spass = spass;
+    if (sc->job_seq == 0 || (!sc->lane_job[0] && !sc->lane_job[1])) {   // nothing in flight: this job has no predecessor to wait for
+        std::lock_guard<std::mutex> lk(sc->job_mu);
+        sc->jobs_recorded = sc->job_seq;
+    }
+    J->seq = sc->job_seq;
+    if (lane == 1) {   // work queued on the caller's stream before this call comes first (lane 0 IS that stream)
+        hipEvent_t e = nullptr;
+        hipError_t he = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        if (he == hipSuccess) he = hipEventRecord(e, sc->ctx->stream);
+        if (he == hipSuccess) he = hipStreamWaitEvent(sc->stream2, e, 0);
+        if (e) (void)hipEventDestroy(e);
+        if (he != hipSuccess) { delete J; return fail(RT_ERR_HIP, hipGetErrorString(he)); }
+    }
+    if (!sc->worker[lane].joinable()) {
+        try { sc->worker[lane] = std::thread(lane_worker, sc, lane); } catch (...) { delete J; return fail(RT_ERR_OOM, "rt_render_begin: cannot start a host thread"); }
+    }
+    { std::lock_guard<std::mutex> lk(sc->job_mu); sc->lane_job[lane] = J; }
+    sc->job_cv.notify_all();
+    sc->job_seq += 1;
+    *out = J;
+    return RT_OK;
+}
+
+int rt_render_end(rt_job* J, rt_stats* stats) {
+    if (!J) return fail(RT_ERR_BAD_ARG, "rt_render_end: null job");
+    rt_scene* sc = J->sc;
+    if (sc->lane_job[J->lane] != J) return fail(RT_ERR_BAD_ARG, "rt_render_end: not a job in flight on its scene");
+    {
+        std::unique_lock<std::mutex> lk(sc->job_mu);
+        sc->job_cv.wait(lk, [&] { return J->finished; });
+        sc->lane_job[J->lane] = nullptr;
+    }
+    int rc = J->rc;
+    if (rc != RT_OK) g_err = J->err;
+    else if (stats) *stats = J->st;
+    delete J;
+    return rc;
+}
+
 int rt_capture_rays(rt_scene* sc, const rt_render_params* p, uint32_t bounce, int shadow, uint32_t stride, uint32_t max_n, uint32_t* n_out, uint32_t* queue_len,
                     double* rays, uint32_t* prim_id, uint32_t* inst_id, double* t, double* t_light) {
     if (!sc || !n_out || !rays || !prim_id || !inst_id || !t || !t_light || stride == 0) return fail(RT_ERR_BAD_ARG, "rt_capture_rays: bad argument");
     int rc = check_params(p);
     if (rc != RT_OK) return rc;
     if (p->spp_end != p->spp_begin + 1) return fail(RT_ERR_BAD_ARG, "rt_capture_rays: exactly one sample index");
+    RT_NOT_BUSY(sc, "rt_capture_rays");
     if ((int32_t)bounce >= p->max_depth) return fail(RT_ERR_BAD_ARG, "rt_capture_rays: bounce >= max_depth");
     HIP_OK(hipSetDevice(sc->ctx->device));
     const uint32_t npix = p->width * p->height;
@@ -3076,6 +3248,7 @@ int rt_sample_radiance(rt_scene* sc, uint32_t width, uint32_t height, uint32_t n
         if (pixel_index[i] >= width * height) return fail(RT_ERR_BAD_ARG, "pixel index out of range");
     HIP_OK(hipSetDevice(sc->ctx->device));
     if (max_depth == 0) { memset(out_rgb, 0, (size_t)n * 3 * sizeof(double)); return RT_OK; }
+    RT_NOT_BUSY(sc, "rt_sample_radiance");
     rc = ws_ensure(sc, n, max_depth);
     if (rc != RT_OK) return rc;
     Workspace& ws = sc->ws;

@@ -9,6 +9,7 @@ the MIS .001 gate -- when a direction moves by 1 ulp).  Image level: 1e-5 relati
 """
 import numpy as np
 import pytest
+import torch  # before the first HIP call of librt_hip.so: torch ships its own ROCm runtime and must initialise first
 
 import oracle_ffi as orc
 import raytracing_amd as rt
@@ -133,6 +134,38 @@ def test_per_lane_walk_gives_the_frame_of_the_wave_walk(gpu_ctx, name, integ, w,
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     assert sa.rays == sb.rays and sb.walk_run_steps > 0 and sa.walk_run_steps == 0
     gs.close()
+
+
+@pytest.mark.parametrize("name,integ", [("random", rt.INT_MIS), ("mesh", rt.INT_BRDF)])
+def test_pipelined_jobs_give_the_frame_of_sequential_calls(gpu_ctx, name, integ):
+    # rt_render_begin / rt_render_end: two calls in flight on the scene's two lanes; each job adds its sums after the job begun before
+    # it, so the accumulator is bit-identical to blocking calls over the same sample ranges with the same pass size
+    hs, _ = _pair(name)
+    gs = gpu_ctx.upload(hs)
+    w, h, chunks = 96, 54, [(0, 3), (3, 7), (7, 8), (8, 13), (13, 15)]
+    ref = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda"); acc = torch.zeros_like(ref)
+    torch.cuda.synchronize()
+    for b, e in chunks:
+        gs.render(ref.data_ptr(), w, h, b, e, 5, integ, seed=9, samples_per_pass=e - b, flags=rt.RENDER_ONE_LANE)
+    pending, stats = [], []
+    for b, e in chunks:
+        pending.append(gs.render_begin(acc.data_ptr(), w, h, b, e, 5, integ, seed=9))
+        if len(pending) == 2:
+            stats.append(gs.render_end(pending.pop(0)))
+    with pytest.raises(rt.RtError, match="in flight"):           # the scene takes no other call while jobs are in flight
+        gs.render(acc.data_ptr(), w, h, 0, 1, 5, integ)
+    while pending:
+        stats.append(gs.render_end(pending.pop(0)))
+    torch.cuda.synchronize()
+    assert torch.equal(ref, acc)
+    assert [s.paths for s in stats] == [w * h * (e - b) for b, e in chunks] and all(s.rays > 0 and s.lanes == 1 for s in stats)
+    with pytest.raises(rt.RtError, match="empty sample range"):
+        gs.render_begin(acc.data_ptr(), w, h, 4, 4, 5, integ)
+    a = gs.render_begin(acc.data_ptr(), w, h, 20, 21, 5, integ); b2 = gs.render_begin(acc.data_ptr(), w, h, 21, 22, 5, integ)
+    with pytest.raises(rt.RtError, match="two jobs"):
+        gs.render_begin(acc.data_ptr(), w, h, 22, 23, 5, integ)
+    gs.close()                                                   # closing the scene ends the jobs nobody waited for
+    del a, b2
 
 
 def test_converged_pagoda_mis_independent_seeds(gpu_ctx):
