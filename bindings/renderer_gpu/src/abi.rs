@@ -267,6 +267,8 @@ extern "C" {
     pub fn rt_resolve_host(accum_host: *const f32, width: u32, height: u32, spp: u32, tonemap: c_int, out_host: *mut f32) -> c_int;
     pub fn rt_sample_radiance(scene: *mut rt_scene, width: u32, height: u32, n: u32, pixel_index: *const u32, sample_index: *const u32, max_depth: i32, integrator: i32,
                               seed: u64, out_rgb: *mut f64) -> c_int;
+    pub fn rt_sample_radiance_sig(scene: *mut rt_scene, width: u32, height: u32, n: u32, pixel_index: *const u32, sample_index: *const u32, max_depth: i32, integrator: i32,
+                                  seed: u64, out_rgb: *mut f64, out_sig: *mut u64) -> c_int;
     pub fn rt_pdf_eval(ctx: *mut rt_context, n: u32, n_comp: u32, pdfs: *const rt_pdf_desc, dirs: *const f64, seed: u64, value: *mut f64, generated: *mut f64) -> c_int;
     pub fn rt_ieee_div_sqrt(ctx: *mut rt_context, n: u32, a: *const f64, b: *const f64, q: *mut f64, s: *mut f64) -> c_int;
     pub fn rt_last_error() -> *const c_char;

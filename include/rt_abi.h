@@ -302,6 +302,13 @@ int rt_resolve_host(const float* accum_host, uint32_t width, uint32_t height, ui
 int rt_sample_radiance(rt_scene* scene, uint32_t width, uint32_t height, uint32_t n, const uint32_t* pixel_index,
                        const uint32_t* sample_index, int32_t max_depth, int32_t integrator, uint64_t seed, double* out_rgb);
 
+/* Same, plus the SIGNATURE of every path (out_sig: n x u64, host): an order-free hash over every discrete decision the path took
+ * (object hit and side per level, checker branch / texel, kind of scatter, reflect or refract, light picked and whether its sample
+ * counted, visible or not, the .001 weight gate; csrc/rt_math.h).  Paths whose signature equals the oracle's followed the same
+ * branches and must agree to rounding; a differing signature explains a deviation.  Test hook, no counterpart in the reference. */
+int rt_sample_radiance_sig(rt_scene* scene, uint32_t width, uint32_t height, uint32_t n, const uint32_t* pixel_index,
+                           const uint32_t* sample_index, int32_t max_depth, int32_t integrator, uint64_t seed, double* out_rgb, uint64_t* out_sig);
+
 /* PDF::value / PDF::generate (renderer/src/pdf.rs:9-15) for n independent items on the device, for parity tests of the
  * PDF set by itself.  Item i is a list of n_comp PDFs pdfs[i*n_comp ..]: n_comp == 1 evaluates that PDF, n_comp in 2..8
  * evaluates MixturePDF with MixtureMethod::Uniform over the list (pdf.rs:185-224: value = sum of value_k / n, generate =

@@ -93,6 +93,17 @@ int orc_sample_radiance(void* scene, uint32_t w, uint32_t h, uint32_t x, uint32_
     ORC_CATCH(-1)
 }
 
+// Same, plus the path's signature (orc_math.hpp): the hash of every discrete decision the sample's path took
+int orc_sample_radiance_sig(void* scene, uint32_t w, uint32_t h, uint32_t x, uint32_t y, uint32_t s, int max_depth, int integrator,
+                            uint64_t seed, double* rgb, uint64_t* sig) {
+    uint64_t acc = 0;
+    g_sig = &acc;
+    int rc = orc_sample_radiance(scene, w, h, x, y, s, max_depth, integrator, seed, rgb);
+    g_sig = nullptr;
+    *sig = acc;
+    return rc;
+}
+
 int orc_resolve(const double* sum_rgb, uint32_t w, uint32_t h, uint32_t spp, int tonemap, double* out_rgb) {
     resolve(sum_rgb, w, h, spp, tonemap, out_rgb);
     return 0;

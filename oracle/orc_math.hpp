@@ -150,6 +150,19 @@ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 
 // Stream of 53-bit uniform doubles in [0,1): counter = (pixel, sample, level, block); each block
 // yields two doubles ((w1:w0)>>11, (w3:w2)>>11) * 2^-53  (rand 0.8 `Standard` f64 conversion).
+// ---- path signatures (tests only; the device computes the same hash, raytracing_amd/csrc/rt_math.h) ---------------------
+// Sum of hashes of (level, tag, value) over every discrete decision of a path; see rt_math.h for the list and the purpose.
+enum { SIG_HIT = 1, SIG_FRONT = 2, SIG_TEX = 3, SIG_KIND = 4, SIG_DELTA = 5, SIG_LIGHT = 6, SIG_VIS = 7, SIG_GATE = 8, SIG_CUT = 9 };
+inline thread_local uint64_t* g_sig = nullptr;   // where the current sample's signature accumulates (null: off)
+inline uint64_t sig_hash(uint32_t level, uint32_t tag, uint64_t value) {
+    uint64_t x = ((uint64_t)level << 56) ^ ((uint64_t)tag << 48) ^ value;
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+inline void sig_event(uint32_t level, uint32_t tag, uint64_t value) { if (g_sig) *g_sig += sig_hash(level, tag, value); }
+
 struct Rng {
     uint32_t k0, k1, pixel, sample, level, draw;
     uint32_t w[4];

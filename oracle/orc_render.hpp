@@ -81,6 +81,25 @@ struct Texture {
             }
         }
     }
+    // signature of sample()'s discrete choices: one bit per checker node on the way down (leading 1), and the texel picked
+    uint64_t sig(double u, double v, V3 p) const {
+        const Texture* t = this;
+        uint64_t bits = 1;
+        for (int depth = 0; depth < 8 && t->kind == CHECKER; ++depth) {
+            double sines = std::sin(10.0 * p.x) * std::sin(10.0 * p.y) * std::sin(10.0 * p.z);
+            bits = (bits << 1) | (sines < 0.0 ? 1u : 0u);
+            t = sines < 0.0 ? t->odd : t->even;
+        }
+        if (t->kind == IMAGE) {
+            double uu = u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
+            double vc = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+            double vv = 1.0 - vc;
+            uint32_t x = sat_u32((double)t->w * uu), y = sat_u32((double)t->h * vv);
+            x = std::min(x, t->w - 1); y = std::min(y, t->h - 1);
+            bits ^= ((uint64_t)y * t->w + x + 1) << 16;
+        }
+        return bits;
+    }
     static uint32_t sat_u32(double d) {  // Rust `as u32`: saturating, NaN -> 0
         if (!(d > 0.0)) return 0;
         if (d >= 4294967295.0) return 4294967295u;
@@ -581,34 +600,58 @@ inline bool light_hit(const Sphere* light, const Ray& ray, double t_min, double 
 
 V3 ray_colour(int integrator, const Ray& ray, const Scene& scene, int depth, const SampleCtx& ctx);
 
+// path-signature events common to the four integrators (tests only; no effect on the arithmetic)
+inline void sig_hit_events(uint32_t level, bool hit, const HitRecord& hr) {
+    if (!g_sig) return;
+    sig_event(level, SIG_HIT, hit ? ((uint64_t)hr.prim_id | ((uint64_t)hr.inst_id << 32)) : 0xFFFFFFFFFFFFFFFFull);
+    if (!hit) return;
+    sig_event(level, SIG_FRONT, hr.front_face ? 1 : 0);
+    if (hr.material->kind == Material::LAMBERTIAN || hr.material->kind == Material::DIFFUSE_LIGHT) sig_event(level, SIG_TEX, hr.material->tex->sig(hr.u, hr.v, hr.point));
+}
+inline void sig_delta_event(uint32_t level, const Pdf& pdf, V3 generated) {   // reflected (1) or refracted (0), pdf.rs:167-173
+    if (g_sig && pdf.kind == Pdf::DIELECTRIC)
+        sig_event(level, SIG_DELTA, (generated.x == pdf.reflect_dir.x && generated.y == pdf.reflect_dir.y && generated.z == pdf.reflect_dir.z) ? 1 : 0);
+}
+
 // integrator.rs:31-171
 inline V3 ray_colour_mis(const Ray& ray, const Scene& scene, int depth, const SampleCtx& ctx) {
     if (depth <= 0) return V3(0.0, 0.0, 0.0);
     Rng rng(ctx.seed, ctx.pixel, ctx.sample, (uint32_t)(ctx.max_depth - depth + 1));
+    const uint32_t level = (uint32_t)(ctx.max_depth - depth);
     HitRecord hr;
-    if (!scene.hit(ray, 0.001, 100000.0, hr)) return background_colour(scene.background, ray);
+    const bool any_hit = scene.hit(ray, 0.001, 100000.0, hr);
+    sig_hit_events(level, any_hit, hr);
+    if (!any_hit) return background_colour(scene.background, ray);
     V3 emitted = hr.material->emitted(hr.u, hr.v, hr.point);
     Pdf material_pdf;
-    if (!hr.material->scattering_pdf(ray, hr, material_pdf)) return emitted;
+    if (!hr.material->scattering_pdf(ray, hr, material_pdf)) { sig_event(level, SIG_KIND, 0); return emitted; }
+    sig_event(level, SIG_KIND, material_pdf.is_delta() ? 1 : 2);
     if (material_pdf.is_delta()) {  // integrator.rs:54-66
-        Ray ray_out{hr.point, normalize(material_pdf.generate(rng)), ray.time};
+        const V3 generated = material_pdf.generate(rng);
+        sig_delta_event(level, material_pdf, generated);
+        Ray ray_out{hr.point, normalize(generated), ray.time};
         double cos_theta = dot(ray_out.dir, hr.normal);
         return emitted + (hr.material->brdf(ray, hr, ray_out) * cos_theta * ray_colour_mis(ray_out, scene, depth - 1, ctx));
     }
     // integrator.rs:68-88
     const Sphere* light = nullptr; Pdf light_pdf; Ray light_ray{};
     if (!scene.lights.empty()) {
-        const Sphere* cand = scene.lights[rng.index((uint32_t)scene.lights.size())];
+        const uint32_t li = rng.index((uint32_t)scene.lights.size());
+        const Sphere* cand = scene.lights[li];
         Pdf lp = cand->pdf_for_point(hr.point);
         V3 dir = normalize(lp.generate(rng));
         Ray visibility_ray{hr.point, dir, ray.time};
+        bool sample_counts = false;   // signature only: the light sample faces the surface and reaches the light's own sphere
         if (!(dot(hr.normal, dir) < 0.0)) {
             HitRecord vis, lh;
+            if (g_sig) { HitRecord tmp; sample_counts = light_hit(cand, visibility_ray, 0.001, 10000.0, tmp); }
             if (scene.hit(visibility_ray, 0.001, 10000.0, vis) && light_hit(cand, visibility_ray, 0.001, 10000.0, lh) &&
                 !(std::fabs(vis.t - lh.t) > 0.0001)) {
                 light = cand; light_pdf = lp; light_ray = visibility_ray;
             }
         }
+        sig_event(level, SIG_LIGHT, 2ull * li + (sample_counts ? 1 : 0));
+        if (sample_counts) sig_event(level, SIG_VIS, light ? 1 : 0);
     }
     if (light) {  // integrator.rs:90-154
         Ray material_out{hr.point, normalize(material_pdf.generate(rng)), ray.time};
@@ -622,6 +665,7 @@ inline V3 ray_colour_mis(const Ray& ray, const Scene& scene, int depth, const Sa
         bool material_ray_hit_light = light_hit(light, material_out, 0.001, 10000.0, tmp);
         V3 material_ray_colour = ray_colour_mis(material_out, scene, depth - 1, ctx);
         bool material_ray_has_light = material_ray_colour.x >= 0.001 && material_ray_colour.y >= 0.001 && material_ray_colour.z >= 0.001;
+        sig_event(level, SIG_GATE, material_ray_has_light ? 1 : 0);
         double material_weight = material_ray_has_light
             ? power_heuristic(1, material_out_pdf, 1, material_ray_hit_light ? light_pdf.value(material_out.dir) : 0.0)
             : 0.0;
@@ -642,18 +686,29 @@ inline V3 ray_colour_mis(const Ray& ray, const Scene& scene, int depth, const Sa
 inline V3 ray_colour_light_is(const Ray& ray, const Scene& scene, int depth, const SampleCtx& ctx) {
     if (depth <= 0) return V3(0.0, 0.0, 0.0);
     Rng rng(ctx.seed, ctx.pixel, ctx.sample, (uint32_t)(ctx.max_depth - depth + 1));
+    const uint32_t level = (uint32_t)(ctx.max_depth - depth);
     HitRecord hr;
-    if (!scene.hit(ray, 0.001, 100000.0, hr)) return background_colour(scene.background, ray);
+    const bool any_hit = scene.hit(ray, 0.001, 100000.0, hr);
+    sig_hit_events(level, any_hit, hr);
+    if (!any_hit) return background_colour(scene.background, ray);
     V3 emitted = hr.material->emitted(hr.u, hr.v, hr.point);
-    if (length(emitted) > 0.0) return emitted;
     Pdf material_pdf;
-    if (!hr.material->scattering_pdf(ray, hr, material_pdf)) return emitted;
+    const bool scatters = hr.material->scattering_pdf(ray, hr, material_pdf);
+    if (!scatters) sig_event(level, SIG_KIND, 0);
+    if (length(emitted) > 0.0) return emitted;
+    if (!scatters) return emitted;
+    sig_event(level, SIG_KIND, material_pdf.is_delta() ? 1 : 2);
     Pdf scatter_pdf = material_pdf;
-    if (!material_pdf.is_delta() && !scene.lights.empty())
-        scatter_pdf = scene.lights[rng.index((uint32_t)scene.lights.size())]->pdf_for_point(hr.point);
+    if (!material_pdf.is_delta() && !scene.lights.empty()) {
+        const uint32_t li = rng.index((uint32_t)scene.lights.size());
+        scatter_pdf = scene.lights[li]->pdf_for_point(hr.point);
+        sig_event(level, SIG_LIGHT, 2ull * li);
+    }
     V3 out_dir = scatter_pdf.generate(rng);
+    sig_delta_event(level, material_pdf, out_dir);
     Ray ray_out{hr.point, out_dir, ray.time};
     double cos_theta = dot(out_dir, hr.normal);
+    sig_event(level, SIG_CUT, cos_theta < 0.0 ? 1 : 0);
     if (cos_theta < 0.0) return emitted;  // integrator.rs:206-215 (the regenerated sample is discarded)
     double pdf = scatter_pdf.is_delta() ? 1.0 : scatter_pdf.value(out_dir);
     V3 brdf = hr.material->brdf(ray, hr, ray_out);
@@ -664,13 +719,18 @@ inline V3 ray_colour_light_is(const Ray& ray, const Scene& scene, int depth, con
 inline V3 ray_colour_path(bool uniform, const Ray& ray, const Scene& scene, int depth, const SampleCtx& ctx) {
     if (depth <= 0) return V3(0.0, 0.0, 0.0);
     Rng rng(ctx.seed, ctx.pixel, ctx.sample, (uint32_t)(ctx.max_depth - depth + 1));
+    const uint32_t level = (uint32_t)(ctx.max_depth - depth);
     HitRecord hr;
-    if (!scene.hit(ray, 0.001, 100000.0, hr)) return background_colour(scene.background, ray);
+    const bool any_hit = scene.hit(ray, 0.001, 100000.0, hr);
+    sig_hit_events(level, any_hit, hr);
+    if (!any_hit) return background_colour(scene.background, ray);
     V3 emitted = hr.material->emitted(hr.u, hr.v, hr.point);
     Pdf material_pdf;
-    if (!hr.material->scattering_pdf(ray, hr, material_pdf)) return emitted;
+    if (!hr.material->scattering_pdf(ray, hr, material_pdf)) { sig_event(level, SIG_KIND, 0); return emitted; }
+    sig_event(level, SIG_KIND, material_pdf.is_delta() ? 1 : 2);
     Pdf scatter_pdf = (uniform && !material_pdf.is_delta()) ? Pdf::uniform_hemi(hr.normal) : material_pdf;
     V3 out_dir = scatter_pdf.generate(rng);
+    sig_delta_event(level, material_pdf, out_dir);
     Ray ray_out{hr.point, out_dir, ray.time};
     double cos_theta = dot(out_dir, hr.normal);
     double pdf = scatter_pdf.is_delta() ? 1.0 : scatter_pdf.value(out_dir);

@@ -273,6 +273,14 @@ class GpuScene:
                                                  seed, out.ctypes.data))
         return out
 
+    def sample_radiance_sig(self, width, height, pixel_index, sample_index, max_depth, integrator, seed=0x5EED):
+        """sample_radiance plus each path's signature (u64): the hash of its discrete decisions (include/rt_abi.h)."""
+        px = np.ascontiguousarray(pixel_index, np.uint32); sm = np.ascontiguousarray(sample_index, np.uint32)
+        out = np.empty((px.size, 3), np.float64); sig = np.empty(px.size, np.uint64)
+        _hip_check(_ffi.hip().rt_sample_radiance_sig(self._h, width, height, px.size, px.ctypes.data, sm.ctypes.data, max_depth, integrator,
+                                                     seed, out.ctypes.data, sig.ctypes.data))
+        return out, sig
+
     def close(self):
         if self._h:
             _ffi.hip().rt_scene_destroy(self._h)

@@ -122,6 +122,7 @@ def hip():
         L.rt_resolve.argtypes = [C.c_void_p, C.c_void_p, u32, u32, u32, C.c_int, C.c_void_p]
         L.rt_resolve_host.argtypes = [C.c_void_p, u32, u32, u32, C.c_int, C.c_void_p]
         L.rt_sample_radiance.argtypes = [C.c_void_p, u32, u32, u32, C.c_void_p, C.c_void_p, i32, i32, u64, C.c_void_p]
+        L.rt_sample_radiance_sig.argtypes = [C.c_void_p, u32, u32, u32, C.c_void_p, C.c_void_p, i32, i32, u64, C.c_void_p, C.c_void_p]
         L.rt_pdf_eval.argtypes = [C.c_void_p, u32, u32, C.c_void_p, C.c_void_p, u64, C.c_void_p, C.c_void_p]
         L.rt_ieee_div_sqrt.argtypes = [C.c_void_p, u32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _hip = L
@@ -130,7 +131,7 @@ def hip():
 
 ABI_SYMBOLS = ["rt_device_count", "rt_context_create", "rt_context_destroy", "rt_context_synchronize", "rt_scene_upload",
                "rt_scene_destroy", "rt_stream_build_host", "rt_stream_build_prod_host", "rt_prune_info_host", "rt_trace_closest", "rt_trace_closest_device", "rt_trace_closest_device_noalloc", "rt_primary_rays", "rt_render", "rt_render_begin", "rt_render_end", "rt_capture_rays",
-               "rt_accum_zero", "rt_render_host", "rt_resolve", "rt_resolve_host", "rt_sample_radiance",
+               "rt_accum_zero", "rt_render_host", "rt_resolve", "rt_resolve_host", "rt_sample_radiance", "rt_sample_radiance_sig",
                "rt_pdf_eval", "rt_ieee_div_sqrt", "rt_last_error"]
 HOST_SYMBOLS = ["rth_set_bvh_axis_seed", "rth_scene_builtin", "rth_scene_from_description", "rth_scene_free",
                 "rth_scene_describe", "rth_scene_flatten", "rth_scene_object_count", "rth_write_ppm", "rth_write_pfm", "rth_write_png",

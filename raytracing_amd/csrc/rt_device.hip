@@ -1389,6 +1389,7 @@ struct PathBuffers {
     double* terminal;    // [3][cap] radiance returned by the last ray_colour level
     double* records;     // [depth][cap][REC_STRIDE]
     double* radiance;    // [3][cap]
+    unsigned long long* sig;  // [cap] path signatures (rt_sample_radiance_sig only; NULL otherwise)
     uint32_t cap;
 };
 
@@ -1475,14 +1476,30 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, PathBuffers pb, cons
         d3 terminal = mk(0.0, 0.0, 0.0);
         bool done = false;
         HitRecord hr;
+        unsigned long long sg = 0ull;   // this level's events (rt_math.h "path signatures"); only summed when pb.sig is set
+        const bool want_sig = pb.sig != nullptr;
+        if (want_sig) {
+            unsigned long long who = 0xFFFFFFFFFFFFFFFFull;
+            if (prim != RT_NONE) {
+                const rt_prim hp = sc.prims[prim];
+                const uint32_t inst_id = ph.inst != RT_NONE ? sc.prims[ph.inst].inst_id : hp.inst_id;
+                who = (unsigned long long)hp.object_id | ((unsigned long long)inst_id << 32);
+            }
+            sg += sig_hash(bounce, SIG_HIT, who);
+        }
         if (prim == RT_NONE) { terminal = background_colour(sc.background, ray); done = true; }  // integrator.rs:39-41
         else if (!full_hit(sc, prim, ph.inst, ray, 0.001, ph.t, hr)) { terminal = mk(__builtin_nan(""), __builtin_nan(""), __builtin_nan("")); done = true; }  // cannot happen: poison loudly
         if (!done) {
             const rt_material mat = sc.materials[hr.material];
             Pdf material_pdf;
+            if (want_sig) {
+                sg += sig_hash(bounce, SIG_FRONT, hr.front_face ? 1ull : 0ull);
+                if (mat.kind == RT_MAT_LAMBERTIAN || mat.kind == RT_MAT_DIFFUSE_LIGHT) sg += sig_hash(bounce, SIG_TEX, tex_sig(sc, mat.texture, hr.u, hr.v, hr.point));
+            }
             if (!scattering_pdf(mat, ray, hr, material_pdf)) {  // DiffuseLight: return emitted (integrator.rs:45-50)
                 terminal = material_emitted(sc, hr.material, hr.u, hr.v, hr.point);
                 done = true;
+                if (want_sig) sg += sig_hash(bounce, SIG_KIND, 0ull);
             } else {
                 const PathInfo pi = pb.info[path];
                 Rng rng(seed, pi.pixel, pi.sample, bounce + 1u);
@@ -1490,9 +1507,12 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, PathBuffers pb, cons
                 d3 brdf, out_dir, c_l = mk(0.0, 0.0, 0.0);
                 double cos_theta, pdf = 1.0, w = 0.0, t_light = nan;
                 const bool delta = pdf_is_delta(material_pdf);
+                if (want_sig) sg += sig_hash(bounce, SIG_KIND, delta ? 1ull : 2ull);
+                d3 gen_dir = mk(0.0, 0.0, 0.0);   // what the scatter pdf generated, before any normalisation (signature: reflect or refract)
                 if (integrator == RT_INT_MIS) {
                     if (delta) {  // integrator.rs:54-66
-                        out_dir = normalize(pdf_generate(material_pdf, rng));
+                        gen_dir = pdf_generate(material_pdf, rng);
+                        out_dir = normalize(gen_dir);
                         cos_theta = dot(out_dir, hr.normal);
                         brdf = material_brdf(sc, mat, hr, out_dir);
                     } else {
@@ -1512,6 +1532,7 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, PathBuffers pb, cons
                                     light_pdf_value = pdf_value(light_pdf, light_dir);
                                 }
                             }
+                            if (want_sig) sg += sig_hash(bounce, SIG_LIGHT, 2ull * li + (have_light ? 1ull : 0ull));
                         }
                         out_dir = normalize(pdf_generate(material_pdf, rng));  // integrator.rs:95 / 158
                         cos_theta = dot(out_dir, hr.normal);
@@ -1538,20 +1559,29 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, PathBuffers pb, cons
                     }
                 } else if (integrator == RT_INT_LIGHT_IS) {  // integrator.rs:187-224 (emitted == 0 here)
                     Pdf scatter_pdf = material_pdf;
-                    if (!delta && sc.n_lights > 0u) scatter_pdf = light_pdf_for_point(sc.lights[rng.index(sc.n_lights)], hr.point);
+                    if (!delta && sc.n_lights > 0u) {
+                        const uint32_t li = rng.index(sc.n_lights);
+                        scatter_pdf = light_pdf_for_point(sc.lights[li], hr.point);
+                        if (want_sig) sg += sig_hash(bounce, SIG_LIGHT, 2ull * li);
+                    }
                     out_dir = pdf_generate(scatter_pdf, rng);
+                    gen_dir = out_dir;
                     cos_theta = dot(out_dir, hr.normal);
                     if (cos_theta < 0.0) { terminal = mk(0.0, 0.0, 0.0); done = true; }
+                    if (want_sig) sg += sig_hash(bounce, SIG_CUT, cos_theta < 0.0 ? 1ull : 0ull);
                     pdf = pdf_is_delta(scatter_pdf) ? 1.0 : pdf_value(scatter_pdf, out_dir);
                     brdf = material_brdf(sc, mat, hr, out_dir);
                 } else {  // integrator.rs:273-291 (BRDF) / 340-361 (uniform)
                     Pdf scatter_pdf = material_pdf;
                     if (integrator == RT_INT_UNIFORM && !delta) { scatter_pdf.kind = PDF_UNIFORM_HEMI; scatter_pdf.a = hr.normal; }
                     out_dir = pdf_generate(scatter_pdf, rng);
+                    gen_dir = out_dir;
                     cos_theta = dot(out_dir, hr.normal);
                     pdf = pdf_is_delta(scatter_pdf) ? 1.0 : pdf_value(scatter_pdf, out_dir);
                     brdf = material_brdf(sc, mat, hr, out_dir);
                 }
+                if (want_sig && material_pdf.kind == PDF_DIELECTRIC)   // reflected (1) or refracted (0): pdf.rs:167-173
+                    sg += sig_hash(bounce, SIG_DELTA, (gen_dir.x == material_pdf.a.x && gen_dir.y == material_pdf.a.y && gen_dir.z == material_pdf.a.z) ? 1ull : 0ull);
                 if (!done) {
                     double* rec = pb.records + ((size_t)bounce * cap + path) * REC_STRIDE;
                     rec[REC_BRDF_X] = brdf.x; rec[REC_BRDF_Y] = brdf.y; rec[REC_BRDF_Z] = brdf.z;
@@ -1571,6 +1601,7 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, PathBuffers pb, cons
                 }
             }
         }
+        if (want_sig) pb.sig[path] += sg;
         if (done) { pb.terminal[(size_t)path * 4u + 0] = terminal.x; pb.terminal[(size_t)path * 4u + 1] = terminal.y; pb.terminal[(size_t)path * 4u + 2] = terminal.z; }
     }
     push_queue_keyed(want_next, path, next_key, next_queue, next_keys, next_count);
@@ -1585,6 +1616,7 @@ __global__ __launch_bounds__(256) void k_unwind(PathBuffers pb, uint32_t n) {
     if (p >= n) return;
     const size_t cap = pb.cap;
     d3 L = mk(pb.terminal[(size_t)p * 4u + 0], pb.terminal[(size_t)p * 4u + 1], pb.terminal[(size_t)p * 4u + 2]);
+    unsigned long long sg = 0ull;
     for (int k = (int)pb.info[p].nb - 1; k >= 0; --k) {
         const double* rec = pb.records + ((size_t)k * cap + p) * REC_STRIDE;
         d3 brdf = mk(rec[REC_BRDF_X], rec[REC_BRDF_Y], rec[REC_BRDF_Z]);
@@ -1593,10 +1625,12 @@ __global__ __launch_bounds__(256) void k_unwind(PathBuffers pb, uint32_t n) {
         if (t_light == t_light) {  // a light sample was taken: visible iff the shadow ray hit and |t_scene - t_light| <= 1e-4 (integrator.rs:82-86)
             double t_shadow = rec[REC_T_SHADOW];
             visible = (t_shadow == t_shadow) && !(fabs(t_shadow - t_light) > 0.0001);
+            sg += sig_hash((uint32_t)k, SIG_VIS, visible ? 1ull : 0ull);
         }
         d3 e = mk(0.0, 0.0, 0.0);  // emitted of a scattering material
         if (visible) {
             bool has_light = L.x >= 0.001 && L.y >= 0.001 && L.z >= 0.001;  // integrator.rs:119-121
+            sg += sig_hash((uint32_t)k, SIG_GATE, has_light ? 1ull : 0ull);
             double w = has_light ? rec[REC_W] : 0.0;
             d3 material_contribution = brdf * cos_theta * L * w / pdf;
             d3 c_l = mk(rec[REC_CL_X], rec[REC_CL_Y], rec[REC_CL_Z]);
@@ -1606,6 +1640,7 @@ __global__ __launch_bounds__(256) void k_unwind(PathBuffers pb, uint32_t n) {
         }
     }
     pb.radiance[0 * cap + p] = L.x; pb.radiance[1 * cap + p] = L.y; pb.radiance[2 * cap + p] = L.z;
+    if (pb.sig) pb.sig[p] += sg;
 }
 
 // per pixel: fixed-order f64 sum over this pass's samples, then one fp32 add into the accumulator
@@ -1921,7 +1956,10 @@ static int capture_queue(Workspace& ws, hipStream_t st, const uint32_t* queue, u
 
 static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bool explicit_lists, uint32_t width, uint32_t height, uint32_t sample0, int32_t max_depth,
                      int32_t integrator, uint64_t seed, bool count_tests, bool sort_rays, EventTimer& tm, uint64_t& launches, uint64_t* shadow_rays = nullptr, Capture* cap = nullptr,
-                     bool lane_walk = false) {
+                     bool lane_walk = false, bool want_sig = false) {
+    PathBuffers pbk = ws.pb;   // what the kernels see: signatures only for rt_sample_radiance_sig
+    if (!want_sig) pbk.sig = nullptr;
+    else HIP_OK(hipMemsetAsync(pbk.sig, 0, (size_t)n * sizeof(unsigned long long), st));
     const bool use_walk = sc->walk_ok && !count_tests && lane_walk;   // opt-in (RT_RENDER_LANE_WALK): bounce >= 1 and shadow rays by the per-lane walk (k_walk)
     const uint32_t npix = width * height;
     tm.begin(CAT_OTHER);
@@ -1949,10 +1987,10 @@ static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bo
         tm.begin(CAT_SHADE);
         // shade appends survivors (and, when sorting, their coherence keys) compactly to the raw queues
         if (sort_rays)
-            hipLaunchKernelGGL(k_shade, grid_for(live), dim3(256), 0, st, sc->dev, ws.pb, ws.queue[cur], ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
+            hipLaunchKernelGGL(k_shade, grid_for(live), dim3(256), 0, st, sc->dev, pbk, ws.queue[cur], ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
                                seed, ws.raw_queue, ws.raw_keys, ws.counts + nxt, ws.raw_squeue, ws.raw_skeys, ws.counts + 2);
         else
-            hipLaunchKernelGGL(k_shade, grid_for(live), dim3(256), 0, st, sc->dev, ws.pb, ws.queue[cur], ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
+            hipLaunchKernelGGL(k_shade, grid_for(live), dim3(256), 0, st, sc->dev, pbk, ws.queue[cur], ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
                                seed, ws.queue[nxt], (uint32_t*)nullptr, ws.counts + nxt, ws.shadow_queue, (uint32_t*)nullptr, ws.counts + 2);
         HIP_OK(hipMemcpyAsync(ws.h_counts, ws.counts, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
@@ -1981,7 +2019,7 @@ static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bo
         live = next_live;
     }
     tm.begin(CAT_OTHER);
-    hipLaunchKernelGGL(k_unwind, grid_for(n), dim3(256), 0, st, ws.pb, n);
+    hipLaunchKernelGGL(k_unwind, grid_for(n), dim3(256), 0, st, pbk, n);
     tm.end();
     launches += 1;
     HIP_OK(hipGetLastError());
@@ -3237,8 +3275,14 @@ int rt_resolve_host(const float* accum_host, uint32_t width, uint32_t height, ui
     return RT_OK;
 }
 
+int rt_sample_radiance_sig(rt_scene* sc, uint32_t width, uint32_t height, uint32_t n, const uint32_t* pixel_index, const uint32_t* sample_index,
+                           int32_t max_depth, int32_t integrator, uint64_t seed, double* out_rgb, uint64_t* out_sig);
 int rt_sample_radiance(rt_scene* sc, uint32_t width, uint32_t height, uint32_t n, const uint32_t* pixel_index, const uint32_t* sample_index,
                        int32_t max_depth, int32_t integrator, uint64_t seed, double* out_rgb) {
+    return rt_sample_radiance_sig(sc, width, height, n, pixel_index, sample_index, max_depth, integrator, seed, out_rgb, nullptr);
+}
+int rt_sample_radiance_sig(rt_scene* sc, uint32_t width, uint32_t height, uint32_t n, const uint32_t* pixel_index, const uint32_t* sample_index,
+                           int32_t max_depth, int32_t integrator, uint64_t seed, double* out_rgb, uint64_t* out_sig) {
     if (!sc || (n && (!pixel_index || !sample_index || !out_rgb))) return fail(RT_ERR_BAD_ARG, "rt_sample_radiance: null argument");
     rt_render_params p{}; p.width = width; p.height = height; p.max_depth = max_depth; p.integrator = integrator;
     int rc = check_params(&p);
@@ -3247,7 +3291,7 @@ int rt_sample_radiance(rt_scene* sc, uint32_t width, uint32_t height, uint32_t n
     for (uint32_t i = 0; i < n; ++i)
         if (pixel_index[i] >= width * height) return fail(RT_ERR_BAD_ARG, "pixel index out of range");
     HIP_OK(hipSetDevice(sc->ctx->device));
-    if (max_depth == 0) { memset(out_rgb, 0, (size_t)n * 3 * sizeof(double)); return RT_OK; }
+    if (max_depth == 0) { memset(out_rgb, 0, (size_t)n * 3 * sizeof(double)); if (out_sig) memset(out_sig, 0, (size_t)n * sizeof(uint64_t)); return RT_OK; }
     RT_NOT_BUSY(sc, "rt_sample_radiance");
     rc = ws_ensure(sc, n, max_depth);
     if (rc != RT_OK) return rc;
@@ -3257,8 +3301,10 @@ int rt_sample_radiance(rt_scene* sc, uint32_t width, uint32_t height, uint32_t n
     HIP_OK(hipMemcpyAsync(ws.in_sample, sample_index, n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     EventTimer tm(st, false);
     uint64_t launches = 0;
-    rc = run_paths(sc, sc->ws, sc->ctx->stream, n, true, width, height, 0, max_depth, integrator, seed, false, sc->sortable, tm, launches);
+    if (out_sig && !ws.pb.sig) { rc = ws_alloc(ws, ws.pb.sig, ws.cap); if (rc != RT_OK) { ws.pb.sig = nullptr; return rc; } }
+    rc = run_paths(sc, sc->ws, sc->ctx->stream, n, true, width, height, 0, max_depth, integrator, seed, false, sc->sortable, tm, launches, nullptr, nullptr, false, out_sig != nullptr);
     if (rc != RT_OK) return rc;
+    if (out_sig) HIP_OK(hipMemcpyAsync(out_sig, ws.pb.sig, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     std::vector<double> rad(3 * (size_t)ws.cap);
     HIP_OK(hipMemcpyAsync(rad.data(), ws.pb.radiance, rad.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));

@@ -86,6 +86,22 @@ struct Rng {
     }
 };
 
+// ---- path signatures (parity tests only: rt_sample_radiance_sig) ----------------------------------
+// Every DISCRETE decision a path takes -- which object a ray hit, which side, which checker branch or texel, which kind of
+// scatter, reflect or refract, which light and whether its sample counted, visible or not, the .001 gate -- is an event
+// (level, tag, value); a path's signature is the sum of the events' hashes (order-free, so the wavefront kernels and the
+// oracle's recursion may meet the events in different orders).  Two paths with equal signatures followed the same branches,
+// so their radiance is a smooth function of the same inputs and must agree to rounding; differing signatures explain a
+// deviation (a direction moved by an ulp of libm across a discontinuity).  The oracle computes the same hash (orc_math.hpp).
+enum { SIG_HIT = 1, SIG_FRONT = 2, SIG_TEX = 3, SIG_KIND = 4, SIG_DELTA = 5, SIG_LIGHT = 6, SIG_VIS = 7, SIG_GATE = 8, SIG_CUT = 9 };
+RT_DEV unsigned long long sig_hash(uint32_t level, uint32_t tag, unsigned long long value) {
+    unsigned long long x = ((unsigned long long)level << 56) ^ ((unsigned long long)tag << 48) ^ value;
+    x += 0x9E3779B97F4A7C15ull;   // splitmix64 finaliser
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
 // ---- math.rs ------------------------------------------------------------------------------------
 RT_DEV d3 rand_in_unit_sphere(Rng& rng) {  // math.rs:12-19 (rejection; each lane loops until accepted)
     for (;;) {

@@ -260,6 +260,25 @@ RT_DEV d3 tex_sample(const SceneDev& sc, uint32_t tex, double u, double v, d3 p)
     }
     return ld3(t.colour);
 }
+// Signature of tex_sample's discrete choices: one bit per checker node on the way down (leading 1), and the texel picked
+RT_DEV unsigned long long tex_sig(const SceneDev& sc, uint32_t tex, double u, double v, d3 p) {
+    rt_texture t = sc.textures[tex];
+    unsigned long long bits = 1ull;
+    for (int depth = 0; depth < 8 && t.kind == RT_TEX_CHECKER; ++depth) {
+        double sines = sin(10.0 * p.x) * sin(10.0 * p.y) * sin(10.0 * p.z);
+        bits = (bits << 1) | (sines < 0.0 ? 1ull : 0ull);
+        t = sc.textures[sines < 0.0 ? t.a : t.b];
+    }
+    if (t.kind == RT_TEX_IMAGE) {
+        double uu = u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
+        double vc = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+        double vv = 1.0 - vc;
+        uint32_t x = sat_u32((double)t.b * uu), y = sat_u32((double)t.c * vv);
+        x = x < t.b - 1 ? x : t.b - 1; y = y < t.c - 1 ? y : t.c - 1;
+        bits ^= ((unsigned long long)y * t.b + x + 1ull) << 16;
+    }
+    return bits;
+}
 // mat_uses_uv[m] != 0 iff material m's texture tree contains an image texture (computed at upload)
 RT_DEV bool material_uses_uv(const SceneDev& sc, uint32_t material) { return sc.mat_uses_uv[material] != 0; }
 

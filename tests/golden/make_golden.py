@@ -30,7 +30,9 @@ def main():
         picks = np.stack([rng.integers(0, w, n), rng.integers(0, h, n), rng.integers(0, 50, n)], 1).astype(np.uint32)
         out[f"{name}_picks"] = picks
         for integ in range(4):
-            out[f"{name}_rad{integ}"] = np.array([osc.sample_radiance(w, h, int(x), int(y), int(s), 5, integ, RAD_SEED) for x, y, s in picks])
+            both = [osc.sample_radiance_sig(w, h, int(x), int(y), int(s), 5, integ, RAD_SEED) for x, y, s in picks]
+            out[f"{name}_rad{integ}"] = np.array([b[0] for b in both])
+            out[f"{name}_sig{integ}"] = np.array([b[1] for b in both], np.uint64)   # path signatures: the discrete decisions each path took
     np.savez_compressed(os.path.join(HERE, "oracle_vectors.npz"), **out)
     print("wrote", os.path.join(HERE, "oracle_vectors.npz"))
 

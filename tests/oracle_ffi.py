@@ -26,6 +26,7 @@ def lib():
         L.orc_primary_rays.argtypes = [C.c_void_p, u32, u32, u32, u64, C.c_void_p]
         L.orc_render.argtypes = [C.c_void_p, u32, u32, u32, u32, C.c_int, C.c_int, u64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_sample_radiance.argtypes = [C.c_void_p, u32, u32, u32, u32, u32, C.c_int, C.c_int, u64, C.c_void_p]
+        L.orc_sample_radiance_sig.argtypes = [C.c_void_p, u32, u32, u32, u32, u32, C.c_int, C.c_int, u64, C.c_void_p, C.c_void_p]
         L.orc_resolve.argtypes = [C.c_void_p, u32, u32, u32, C.c_int, C.c_void_p]
         L.orc_quantize_ppm.argtypes = [C.c_void_p, u32, u32, C.c_void_p]
         L.orc_bvh_dump.restype = C.c_int64
@@ -98,6 +99,11 @@ class OracleScene:
         out = np.zeros(3, np.float64)
         self._chk(lib().orc_sample_radiance(self._h, w, h, x, y, s, max_depth, integrator, seed, out.ctypes.data))
         return out
+
+    def sample_radiance_sig(self, w, h, x, y, s, max_depth, integrator, seed=0x5EED):
+        out = np.zeros(3); sig = u64(0)
+        self._chk(lib().orc_sample_radiance_sig(self._h, w, h, x, y, s, max_depth, integrator, seed, out.ctypes.data, C.byref(sig)))
+        return out, int(sig.value)
 
     def bvh_dump(self, obj_id=0xFFFFFFFF):
         n = lib().orc_bvh_dump(self._h, obj_id, None, None)

@@ -192,10 +192,12 @@ def test_gpu_matches_committed_golden_vectors(gpu_ctx):
         assert list(map(int, cnt[:3])) == list(map(int, g[f"{name}_cnt"][:3])) and int(cnt[3]) == 0
         picks = g[f"{name}_picks"]
         for integ in range(4):
-            got = gs.sample_radiance(w, h, picks[:, 1] * w + picks[:, 0], picks[:, 2], 5, integ, 77)
-            ref = g[f"{name}_rad{integ}"]
-            ok = (np.abs(got - ref) <= 1e-9 * (np.abs(ref) + 1e-3)) | (np.isnan(got) & np.isnan(ref))
-            assert ok.all(axis=1).mean() >= 0.97, (name, integ)
+            got, sig = gs.sample_radiance_sig(w, h, picks[:, 1] * w + picks[:, 0], picks[:, 2], 5, integ, 77)
+            ref, ref_sig = g[f"{name}_rad{integ}"], g[f"{name}_sig{integ}"]
+            ok = ((np.abs(got - ref) <= 1e-9 * (np.abs(ref) + 1e-3)) | (np.isnan(got) & np.isnan(ref))).all(axis=1)
+            # a sample may leave the tolerance only if its path took another discrete decision than the frozen oracle path (signature)
+            assert not (~ok & (sig == ref_sig)).any(), (name, integ, np.flatnonzero(~ok & (sig == ref_sig)))
+            assert (sig != ref_sig).mean() <= 0.05, (name, integ, (sig != ref_sig).mean())
         gs.close()
 
 

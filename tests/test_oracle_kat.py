@@ -134,3 +134,18 @@ def test_furnace_lambertian():
     img, st = sc.render(16, 9, 0, 8, 4, 2)
     centre = img[4, 8] / 8
     assert np.allclose(centre, [0.25, 0.5, 0.75], rtol=1e-12)
+
+
+def test_path_signature_marks_discrete_decisions():
+    # oracle side of the path signatures used by the GPU radiance tests: deterministic, different for different paths, and the
+    # instrumentation leaves the radiance untouched (tests/golden keeps the radiance arrays of the uninstrumented oracle bit for bit)
+    import raytracing_amd as rt
+    osc = orc.OracleScene(rt.HostScene.builtin("random", bvh_seed=5).describe())
+    a = [osc.sample_radiance_sig(48, 27, x, 13, 3, 6, 0, 77) for x in range(48)]
+    b = [osc.sample_radiance_sig(48, 27, x, 13, 3, 6, 0, 77) for x in range(48)]
+    assert [s for _, s in a] == [s for _, s in b]
+    for (ra, _), x in zip(a, range(48)):
+        assert np.array_equal(ra, osc.sample_radiance(48, 27, x, 13, 3, 6, 0, 77), equal_nan=True)
+    assert len({s for _, s in a}) > 24
+    # depth 0 takes no decision at all
+    assert osc.sample_radiance_sig(48, 27, 5, 5, 0, 0, 0, 77)[1] == 0
