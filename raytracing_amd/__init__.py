@@ -16,7 +16,7 @@ from ._ffi import ASSETS, RenderParams, Stats
 INT_MIS, INT_LIGHT_IS, INT_BRDF, INT_UNIFORM = 0, 1, 2, 3
 INTEGRATORS = {"mis": INT_MIS, "light_is": INT_LIGHT_IS, "brdf": INT_BRDF, "uniform": INT_UNIFORM}
 NONE = 0xFFFFFFFF
-RENDER_COUNT_TESTS, RENDER_NO_SORT, RENDER_ONE_LANE, RENDER_LANE_WALK = 1, 2, 4, 8
+RENDER_COUNT_TESTS, RENDER_NO_SORT, RENDER_ONE_LANE, RENDER_LANE_WALK, RENDER_MATERIAL_BINS = 1, 2, 4, 8, 16
 NOALLOC_MAX_RAYS = 262144
 PDF_COSINE, PDF_UNIFORM_HEMI, PDF_UNIFORM_SPHERE, PDF_FUZZY, PDF_DIELECTRIC, PDF_CONE = range(6)
 PDF_DESC = np.dtype([("kind", "<u4"), ("cannot_refract", "<u4"), ("a", "<f8", 3), ("b", "<f8", 3), ("s", "<f8")])   # rt_pdf_desc, 64 B

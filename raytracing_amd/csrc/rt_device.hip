@@ -1454,7 +1454,86 @@ RT_DEV void push_queue(bool want, uint32_t path, uint32_t* __restrict__ queue, u
     if (want) queue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = path;
 }
 
-__global__ __launch_bounds__(256) void k_shade(SceneDev sc, PathBuffers pb, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr,
+// ---- ray-queue compaction BY MATERIAL (scenes with more than one kind of scattering material) ---------------------------------
+// k_shade's cost per wave is the sum of the material branches its 64 paths take (Lambertian: cosine pdf + light sample; Metal: a
+// rejection loop; Dielectric: Fresnel; DiffuseLight and misses: terminal).  After a traversal launch the queue's slots are therefore
+// regrouped by the class of what they hit -- 0 miss, 1 + rt_material.kind otherwise -- so that a wave shades one class:
+// Three launches, no atomics, stable (slots of one class keep their queue order, so the sort's coherence survives and the order is
+// a pure function of the queue): k_bin_count -- a wave takes `rounds` x 64 consecutive slots, writes each slot's class byte and its five
+// ballot-popcount totals to unit_counts[class][unit]; k_bin_scan -- ONE workgroup turns that class-major table into its exclusive prefix
+// (= class base + the unit's offset inside the class); k_bin_scatter -- the same waves replay their class bytes and place each slot at
+// base[class] + prefix popcount of its ballot.  `order[i]` = queue slot shaded by thread i (hit records stay indexed by slot).
+// (A first version with one device-scope atomic per wave and class was 5x SLOWER than not binning: same-address atomics from 8 XCDs
+// serialise at about 12 ns each.)
+#define RT_N_CLASSES 5u
+RT_DEV uint32_t hit_class(const SceneDev& sc, const PathHit& ph) {
+    if (ph.prim == RT_NONE) return 0u;
+    return 1u + sc.materials[sc.prims[ph.prim].material].kind;
+}
+__global__ __launch_bounds__(256) void k_bin_count(SceneDev sc, const PathHit* __restrict__ hit, uint32_t n, uint32_t nunits, uint32_t rounds,
+                                                   uint8_t* __restrict__ cls, uint32_t* __restrict__ unit_counts) {
+    const uint32_t unit = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = lane_id();
+    if (unit >= nunits) return;
+    uint32_t cnt[RT_N_CLASSES] = {0u, 0u, 0u, 0u, 0u};
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t slot = (unit * rounds + r) * 64u + lane;
+        uint32_t c = RT_N_CLASSES;
+        if (slot < n) { c = hit_class(sc, hit[slot]); cls[slot] = (uint8_t)c; }
+#pragma unroll
+        for (uint32_t k = 0; k < RT_N_CLASSES; ++k) cnt[k] += (uint32_t)__popcll(__ballot(c == k));
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < RT_N_CLASSES; ++k) if (lane == k) unit_counts[(size_t)k * nunits + unit] = cnt[k];
+}
+// exclusive prefix of `total` counts in place, one workgroup of 1024 threads, 4 entries per thread and tile, carry across tiles
+__global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ v, uint32_t total) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    if (tid == 0) carry_s = 0u;
+    __syncthreads();
+    for (uint32_t t0 = 0; t0 < total; t0 += 4096u) {
+        const uint32_t i = t0 + tid * 4u;
+        uint32_t e[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) e[k] = i + k < total ? v[i + k] : 0u;
+        const uint32_t mine = e[0] + e[1] + e[2] + e[3];
+        uint32_t inc = mine;   // inclusive scan inside the wave
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += o; }
+        if (lane == 63u) wsum[w] = inc;
+        __syncthreads();
+        uint32_t before = carry_s;
+        for (uint32_t k = 0; k < w; ++k) before += wsum[k];
+        uint32_t run = before + inc - mine;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) { if (i + k < total) v[i + k] = run; run += e[k]; }
+        __syncthreads();
+        if (tid == 1023u) carry_s = run;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_bin_scatter(const uint8_t* __restrict__ cls, uint32_t n, uint32_t nunits, uint32_t rounds,
+                                                     const uint32_t* __restrict__ unit_base, uint32_t* __restrict__ order) {
+    const uint32_t unit = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = lane_id();
+    if (unit >= nunits) return;
+    uint32_t base[RT_N_CLASSES];
+#pragma unroll
+    for (uint32_t k = 0; k < RT_N_CLASSES; ++k) base[k] = unit_base[(size_t)k * nunits + unit];
+    const uint64_t below = (1ull << lane) - 1ull;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t slot = (unit * rounds + r) * 64u + lane;
+        const uint32_t c = slot < n ? (uint32_t)cls[slot] : RT_N_CLASSES;
+#pragma unroll
+        for (uint32_t k = 0; k < RT_N_CLASSES; ++k) {
+            const uint64_t m = __ballot(c == k);
+            if (c == k) order[base[k] + (uint32_t)__popcll(m & below)] = slot;
+            base[k] += (uint32_t)__popcll(m);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_shade(SceneDev sc, PathBuffers pb, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ order, const uint32_t* __restrict__ n_ptr,
                                                uint32_t bounce, int32_t max_depth, int32_t integrator, uint64_t seed,
                                                uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_keys, uint32_t* __restrict__ next_count,
                                                uint32_t* __restrict__ shadow_queue, uint32_t* __restrict__ shadow_keys, uint32_t* __restrict__ shadow_count) {
@@ -1466,12 +1545,13 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, PathBuffers pb, cons
     bool want_next = false, want_shadow = false;
     uint32_t path = 0, next_key = 0, shadow_key = 0;
     if (valid) {
-        path = queue[gid];
+        const uint32_t slot = order ? order[gid] : gid;   // material-binned order (k_bin_scatter) or the queue's own
+        path = queue[slot];
         Ray ray;
         const double4* r4 = (const double4*)(pb.rays + (size_t)path * RT_RAY_STRIDE);
         const double4 ra = r4[0], rb = r4[1];
         ray.o = mk(ra.x, ra.y, ra.z); ray.d = mk(ra.w, rb.x, rb.y); ray.time = rb.z;
-        const PathHit ph = pb.hit[gid];   // written by k_trace per slot of this queue
+        const PathHit ph = pb.hit[slot];   // written by k_trace per slot of this queue
         const uint32_t prim = ph.prim;
         d3 terminal = mk(0.0, 0.0, 0.0);
         bool done = false;
@@ -1739,6 +1819,9 @@ struct Workspace {
     uint32_t* raw_queue = nullptr; uint32_t* raw_keys = nullptr; uint32_t* raw_squeue = nullptr; uint32_t* raw_skeys = nullptr; uint32_t* sorted_keys = nullptr;  // ray sorting
     void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     uint32_t cap = 0; int32_t depth = 0;
+    uint32_t* order = nullptr;      // material-binned shading order of the current queue (k_bin_scatter)
+    uint8_t* cls = nullptr;         // class byte per queue slot (k_bin_count)
+    uint32_t* bins = nullptr;       // [class][unit] counts, then their exclusive prefix (k_bin_count / k_bin_scan)
     uint4* walk_state = nullptr;    // k_walk: [RT_WALK_STATE_VEC][cap] per-ray filter state (k_walk_setup)
     uint32_t* walk_odd = nullptr;   // queue slots k_walk leaves to k_trace (rays that need the literal box test)
     uint32_t* walk_ctr = nullptr;   // [0] next queue slot to hand out, [1] entries of walk_odd
@@ -1767,6 +1850,7 @@ struct rt_scene {
     bool reg_ray = false;   // most leaves are not triangles: k_trace variant with the f64 ray in registers
     bool sortable = false;  // scene has a finite box to quantise ray origins against
     bool walk_ok = false;   // k_walk (per-lane walk) may trace this scene's secondary and shadow rays
+    bool bin_materials = false;  // more than one kind of scattering material: shade in material-binned order
     int n_cu = 256;
     Workspace ws;
     Workspace ws2;                  // second render lane (rt_render runs two passes at a time, each on its own stream)
@@ -1956,7 +2040,7 @@ static int capture_queue(Workspace& ws, hipStream_t st, const uint32_t* queue, u
 
 static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bool explicit_lists, uint32_t width, uint32_t height, uint32_t sample0, int32_t max_depth,
                      int32_t integrator, uint64_t seed, bool count_tests, bool sort_rays, EventTimer& tm, uint64_t& launches, uint64_t* shadow_rays = nullptr, Capture* cap = nullptr,
-                     bool lane_walk = false, bool want_sig = false) {
+                     bool lane_walk = false, bool want_sig = false, bool bins = false) {
     PathBuffers pbk = ws.pb;   // what the kernels see: signatures only for rt_sample_radiance_sig
     if (!want_sig) pbk.sig = nullptr;
     else HIP_OK(hipMemsetAsync(pbk.sig, 0, (size_t)n * sizeof(unsigned long long), st));
@@ -1985,12 +2069,27 @@ static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bo
         const bool mis_shadow = integrator == RT_INT_MIS && sc->dev.n_lights > 0;
         const bool last_bounce = bounce + 1 >= max_depth;
         tm.begin(CAT_SHADE);
+        const uint32_t* order = nullptr;
+        if (sc->bin_materials && bins) {   // opt-in (RT_RENDER_MATERIAL_BINS): regroup the queue's slots by the material class of their hits (compaction by material)
+            if (!ws.order) {   // first use on this workspace (freed with it)
+                int rc;
+                if ((rc = ws_alloc(ws, ws.order, ws.cap)) != RT_OK || (rc = ws_alloc(ws, ws.cls, ws.cap)) != RT_OK ||
+                    (rc = ws_alloc(ws, ws.bins, (size_t)RT_N_CLASSES * ((ws.cap + 511) / 512) + 16)) != RT_OK) return rc;
+            }
+            const uint32_t rounds = live > (8u << 20) ? 32u : 8u, nunits = (live + rounds * 64u - 1u) / (rounds * 64u);
+            const dim3 ugrid((nunits + 3u) / 4u);
+            hipLaunchKernelGGL(k_bin_count, ugrid, dim3(256), 0, st, sc->dev, ws.pb.hit, live, nunits, rounds, ws.cls, ws.bins);
+            hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, ws.bins, RT_N_CLASSES * nunits);
+            hipLaunchKernelGGL(k_bin_scatter, ugrid, dim3(256), 0, st, ws.cls, live, nunits, rounds, ws.bins, ws.order);
+            order = ws.order;
+            launches += 3;
+        }
         // shade appends survivors (and, when sorting, their coherence keys) compactly to the raw queues
         if (sort_rays)
-            hipLaunchKernelGGL(k_shade, grid_for(live), dim3(256), 0, st, sc->dev, pbk, ws.queue[cur], ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
+            hipLaunchKernelGGL(k_shade, grid_for(live), dim3(256), 0, st, sc->dev, pbk, ws.queue[cur], order, ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
                                seed, ws.raw_queue, ws.raw_keys, ws.counts + nxt, ws.raw_squeue, ws.raw_skeys, ws.counts + 2);
         else
-            hipLaunchKernelGGL(k_shade, grid_for(live), dim3(256), 0, st, sc->dev, pbk, ws.queue[cur], ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
+            hipLaunchKernelGGL(k_shade, grid_for(live), dim3(256), 0, st, sc->dev, pbk, ws.queue[cur], order, ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
                                seed, ws.queue[nxt], (uint32_t*)nullptr, ws.counts + nxt, ws.shadow_queue, (uint32_t*)nullptr, ws.counts + 2);
         HIP_OK(hipMemcpyAsync(ws.h_counts, ws.counts, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
@@ -2683,6 +2782,12 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     ctx->live_scenes += 1;
     sc->host_prims.assign(prims, prims + h.n_prims);
     sc->has_instances = P.has_instances; sc->reg_ray = P.reg_ray;
+    {   // kinds of scattering material in the scene (DiffuseLight terminates a path; it is a class of its own but no reason to bin)
+        const rt_material* mats = (const rt_material*)(b + h.off_materials);
+        uint32_t kinds = 0;
+        for (uint32_t i = 0; i < h.n_materials; ++i) if (mats[i].kind != RT_MAT_DIFFUSE_LIGHT) kinds |= 1u << mats[i].kind;
+        sc->bin_materials = __builtin_popcount(kinds) > 1;
+    }
 #ifndef RT_TRACE_DIAG   /* the diagnostic build reports k_trace's own step counts */
     sc->walk_ok = P.walk_ok;
 #endif
@@ -2984,7 +3089,8 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
         for (uint32_t k = (uint32_t)li; k < n_pass; k += (uint32_t)n_lanes) {
             const uint32_t s0 = p->spp_begin + k * spass;
             const uint32_t ns = std::min(spass, p->spp_end - s0);
-            int r = run_paths(sc, ws, L.st, npix * ns, false, p->width, p->height, s0, p->max_depth, p->integrator, p->seed, count_tests, sort_rays, L.tm, L.launches, &L.shadow_rays, nullptr, (p->flags & RT_RENDER_LANE_WALK) != 0);
+            int r = run_paths(sc, ws, L.st, npix * ns, false, p->width, p->height, s0, p->max_depth, p->integrator, p->seed, count_tests, sort_rays, L.tm, L.launches, &L.shadow_rays, nullptr, (p->flags & RT_RENDER_LANE_WALK) != 0, false,
+                              (p->flags & RT_RENDER_MATERIAL_BINS) != 0);
             if (r != RT_OK) return r;
             if (k > 0) {
                 std::unique_lock<std::mutex> lk(mu);
@@ -3075,7 +3181,7 @@ static void job_main(rt_job* J) {
         for (uint32_t s0 = p.spp_begin; s0 < p.spp_end; s0 += J->spass) {
             const uint32_t ns = std::min(J->spass, p.spp_end - s0);
             int r = run_paths(sc, ws, st, npix * ns, false, p.width, p.height, s0, p.max_depth, p.integrator, p.seed, false, sort_rays, tm, launches, &shadow_rays, nullptr,
-                              (p.flags & RT_RENDER_LANE_WALK) != 0);
+                              (p.flags & RT_RENDER_LANE_WALK) != 0, false, (p.flags & RT_RENDER_MATERIAL_BINS) != 0);
             if (r != RT_OK) return r;
             if (!waited) {   // the job begun before this one adds its sums first (fixed order of the fp32 additions)
                 std::unique_lock<std::mutex> lk(sc->job_mu);

@@ -145,6 +145,21 @@ def test_per_lane_walk_gives_the_frame_of_the_wave_walk(gpu_ctx, name, integ, w,
     gs.close()
 
 
+@pytest.mark.parametrize("name,integ,depth", [("random", rt.INT_MIS, 12), ("simple", rt.INT_BRDF, 6), ("sphere", rt.INT_LIGHT_IS, 5)])
+def test_material_binned_shading_gives_the_frame_of_queue_order(gpu_ctx, name, integ, depth):
+    # opt-in RT_RENDER_MATERIAL_BINS: before every shade launch the queue's slots are regrouped by the material class of their hits
+    # (stable partition: ballots + prefix sums, k_bin_count / k_bin_scan / k_bin_scatter).  A path's radiance does not depend on where
+    # in the launch it is shaded, so the frame is bit-identical to shading in queue order.
+    hs, _ = _pair(name)
+    gs = gpu_ctx.upload(hs)
+    w, h = 160, 90
+    a, sa = gs.render_host(w, h, 0, 5, depth, integ, seed=3, flags=rt.RENDER_MATERIAL_BINS)
+    b, sb = gs.render_host(w, h, 0, 5, depth, integ, seed=3)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert sa.rays == sb.rays and sa.launches > sb.launches     # the three binning launches per bounce are counted
+    gs.close()
+
+
 @pytest.mark.parametrize("name,integ", [("random", rt.INT_MIS), ("mesh", rt.INT_BRDF)])
 def test_pipelined_jobs_give_the_frame_of_sequential_calls(gpu_ctx, name, integ):
     # rt_render_begin / rt_render_end: two calls in flight on the scene's two lanes; each job adds its sums after the job begun before
