@@ -60,6 +60,11 @@ def parse_args(argv=None):
     ap.add_argument("--one-lane", action="store_true")            # A/B: the passes of a call one after the other
     ap.add_argument("--sync-steps", action="store_true")          # A/B: every step a blocking rt_render (two lanes inside the call) instead of two steps in flight
     ap.add_argument("--bvh-seed", type=int, default=3)
+    # bvh.rs:53 draws every split axis from an unseeded RNG, so the reference's tree differs from run to run and every axis assignment is
+    # one of its trees.  min_area (default): per node the axis, of those three, whose median split has the least area x count
+    # (include/rt_host.h); seeded: the splitmix64 stream of --bvh-seed, as in the parity suites.  Parity is tested on both.
+    ap.add_argument("--bvh-axis", default="min_area", choices=("min_area", "seeded"))
+    ap.add_argument("--no-seeded-compare", action="store_true")   # skip the extra (untimed) steps on the seeded-axis tree
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"))  # gloo + --renderer: the CPU test of the N-rank plumbing
@@ -94,13 +99,13 @@ def spawn_ranks(args):
 class HipRenderer:
     """The product path: librt_hip.so through raytracing_amd (raises if the library is missing)."""
 
-    def __init__(self, args, rank, world, local_rank, dev, rtd):
+    def __init__(self, args, rank, world, local_rank, dev, rtd, bvh_axis=None):
         import raytracing_amd as rt
         self.rt = rt
         scene, legacy_bvh, self.W, self.H, self.integrator, self.depth = WORKLOADS[args.workload]
         blob, self.desc, self.prune = b"", None, None
         if rank == 0:  # built and flattened once, broadcast as bytes, uploaded per rank
-            hs = rt.HostScene.builtin(scene, bvh_seed=args.bvh_seed, legacy_bvh=legacy_bvh)
+            hs = rt.HostScene.builtin(scene, bvh_seed=args.bvh_seed, legacy_bvh=legacy_bvh, bvh_axis=bvh_axis or args.bvh_axis)
             blob, self.desc, self.prune = hs.blob(), hs.describe(), hs.prune_info()
         blob = rtd.broadcast_blob(blob, dev)
         self.ctx = rt.Context(local_rank)
@@ -253,7 +258,7 @@ def main():
             "config": {"workload": args.workload, "scene": scene, "width": W, "height": H, "integrator": INTEGRATOR_NAMES[integrator],
                        "max_depth": depth, "spp_per_step": spp_step, "render_lanes": 1 if args.one_lane else 2, "spp_total": spp_total,
                        "steps_in_flight": 2 if pipelined else 1,
-                       "sharding": f"spp-range x{world}" if world > 1 else "none", "bvh_seed": args.bvh_seed},
+                       "sharding": f"spp-range x{world}" if world > 1 else "none", "bvh_seed": args.bvh_seed, "bvh_axis": args.bvh_axis},
             "paths_per_s": paths_all / t_max, "rays": rays_all, "paths": paths_all,
             "accum_checksum": float(accum.double().sum()),
         }
@@ -262,12 +267,35 @@ def main():
             if world == 1 and not args.no_cpu_baseline:
                 threads = args.cpu_threads or min(16, os.cpu_count() or 1)
                 out["cpu_baseline"] = cpu_baseline(R.desc, integrator, depth, threads)
-        print(json.dumps(out), flush=True)
     R.close()
+    if rank == 0:
+        if world == 1 and not args.renderer and args.bvh_axis != "seeded" and not args.no_seeded_compare:
+            out["seeded_tree"] = seeded_compare(args, local_rank, dev, rtd, accum, sync, spp_step)
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     return rc
+
+
+def seeded_compare(args, local_rank, dev, rtd, accum, sync, spp_step):
+    """After the timed region and after its scene is closed: the same steps on the tree of the seeded axis stream (the tree of the
+    parity suites and of rounds 1-2a), two warm-up and four timed steps, so the line shows what the axis choice is worth."""
+    R = HipRenderer(args, 0, 1, local_rank, dev, rtd, bvh_axis="seeded")
+    try:
+        def pair(b):
+            jobs = [R.begin(accum, b, b + spp_step), R.begin(accum, b + spp_step, b + 2 * spp_step)]
+            return [R.end(j) for j in jobs]
+        pair(0); sync()
+        t0 = time.perf_counter()
+        st = pair(2 * spp_step) + pair(4 * spp_step)
+        sync()
+        dt = time.perf_counter() - t0
+    finally:
+        R.close()
+    rays = sum(s["rays"] for s in st)
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "steps": 4, "bvh_axis": "seeded", "bvh_seed": args.bvh_seed,
+            "note": "same workload on the tree built from the seeded axis stream; untimed extra, not part of `value`"}
 
 
 def report_kernels(args, R, accum, stats, step_range, rays, spp_step):
@@ -301,7 +329,8 @@ def report_kernels(args, R, accum, stats, step_range, rays, spp_step):
     if os.path.exists(pmc_path):
         try:
             pm = json.load(open(pmc_path))
-            if pm.get("workload") == args.workload and pm.get("spp_per_step") == alone["samples_per_pass"]:   # counters of a pass of this size
+            if (pm.get("workload") == args.workload and pm.get("spp_per_step") == alone["samples_per_pass"]
+                    and pm.get("bvh_axis", "seeded") == args.bvh_axis):   # counters of a pass of this size on this tree
                 traffic = pm.get("hbm_bytes_per_launch")
                 pmc = {k: pm[k] for k in ("valu_issue_utilisation", "scalar_issue_utilisation", "valu_insts_per_ray", "lane_use_by_launch",
                                           "measured_hbm_frac", "spp_per_step", "source") if k in pm}

@@ -9,6 +9,7 @@
 //! write_image(&img, "output.ppm");                                             // exporters/ppm.rs, unchanged
 //! ```
 pub mod abi;
+pub mod bvh_axis;
 pub mod flatten;
 
 use abi::*;

@@ -15,6 +15,13 @@ typedef struct rth_scene rth_scene;
 
 /* Seed of the BVH split-axis stream (replaces thread_rng at bvh.rs:53) for scenes built afterwards. */
 void rth_set_bvh_axis_seed(uint64_t seed);
+/* Where a BVH build takes its split axes from, for scenes built afterwards.  bvh.rs:53 draws them from an UNSEEDED thread_rng, so every
+ * assignment of axes is a tree the reference can build.  0 (default): the seeded stream above.  1: at every node the axis, of the three,
+ * whose median split (bvh.rs:55-77 unchanged) has the smallest area(left)*|left| + area(right)*|right| (host/renderer.hpp).  Returns 0,
+ * -1 for an unknown mode.  The scene description records the mode (`bvh_axis_mode 1`), so the oracle builds the same tree. */
+#define RTH_BVH_AXIS_SEEDED 0u
+#define RTH_BVH_AXIS_MIN_AREA 1u
+int rth_set_bvh_axis_mode(uint32_t mode);
 
 /* One of the reference scene functions by name: "random" (create_random_scene(false), main.rs:365),
  * "random_blur", "mesh" (mesh_scene, main.rs:789), "simple" (create_simple_scene, main.rs:281),

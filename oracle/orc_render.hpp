@@ -449,9 +449,12 @@ struct Transformed : Hittable {
 // The reference draws the split axis from thread_rng (bvh.rs:53), so its tree differs per run.
 // The oracle injects the axis sequence: splitmix64 stream, axis = (next >> 33) % 3, drawn at node
 // entry (pre-order), only for slices of length >= 3 -- exactly where bvh.rs:53 draws.
+// Any axis sequence is a tree the reference can build.  mode 1 ("min area"): instead of drawing, a node takes the axis whose median
+// split -- the one bvh.rs:55-77 would make for that axis -- minimises  sum over the two halves of  half_area(box of the half) * count,
+// half_area = dx*dy + dy*dz + dz*dx; axis 0 unless a later axis is strictly cheaper.
 struct AxisRng {
-    uint64_t s;
-    explicit AxisRng(uint64_t seed) : s(seed) {}
+    uint64_t s; uint32_t mode;
+    explicit AxisRng(uint64_t seed, uint32_t mode_ = 0) : s(seed), mode(mode_) {}
     uint32_t next_axis() {
         s += 0x9E3779B97F4A7C15ull;
         uint64_t z = s;
@@ -479,15 +482,37 @@ struct BVHNode : Hittable {
             if (!list_bounding_box(hittables, n, time_0, time_1, bbox)) throw std::runtime_error("unbounded object in BVH");
             return;
         }
-        uint32_t sort_axis = rng.next_axis();
-        struct Key { double k; Hittable* h; };
+        struct Key { double k; Hittable* h; AABB box; };
         std::vector<Key> keys(n);
-        for (size_t i = 0; i < n; ++i) {
-            AABB b;
-            if (!hittables[i]->bounding_box(time_0, time_1, b)) throw std::runtime_error("unbounded object in BVH");
-            keys[i] = Key{b.min[(int)sort_axis], hittables[i]};
+        auto sorted_on = [&](int axis) {   // bvh.rs:55-73 for one axis
+            std::vector<Key> out(n);
+            for (size_t i = 0; i < n; ++i) {
+                AABB b;
+                if (!hittables[i]->bounding_box(time_0, time_1, b)) throw std::runtime_error("unbounded object in BVH");
+                out[i] = Key{b.min[axis], hittables[i], b};
+            }
+            std::stable_sort(out.begin(), out.end(), [](const Key& a, const Key& b) { return a.k < b.k; });
+            return out;
+        };
+        if (rng.mode == 0) keys = sorted_on((int)rng.next_axis());
+        else {
+            double cheapest = 0.0;
+            for (int axis = 0; axis < 3; ++axis) {
+                std::vector<Key> cand = sorted_on(axis);
+                double total = 0.0;
+                const size_t cut[3] = {0, n / 2, n};
+                for (int half = 0; half < 2; ++half) {
+                    double lo[3], hi[3];
+                    for (int k = 0; k < 3; ++k) { lo[k] = cand[cut[half]].box.min[k]; hi[k] = cand[cut[half]].box.max[k]; }
+                    for (size_t i = cut[half] + 1; i < cut[half + 1]; ++i)
+                        for (int k = 0; k < 3; ++k) { lo[k] = std::fmin(lo[k], cand[i].box.min[k]); hi[k] = std::fmax(hi[k], cand[i].box.max[k]); }
+                    const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+                    const double part = (dx * dy + dy * dz + dz * dx) * (double)(cut[half + 1] - cut[half]);
+                    total = half == 0 ? part : total + part;
+                }
+                if (axis == 0 || total < cheapest) { cheapest = total; keys = std::move(cand); }
+            }
         }
-        std::stable_sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) { return a.k < b.k; });
         std::vector<Hittable*> objects(n);
         for (size_t i = 0; i < n; ++i) objects[i] = keys[i].h;
         size_t midpoint = n / 2;
@@ -570,6 +595,7 @@ struct Scene {
     int background = BG_BLACK;
     std::unique_ptr<BVHNode> bvh;                 // scene.rs:16
     uint64_t bvh_seed = 0;
+    uint32_t bvh_axis_mode = 0;   // 0: seeded axis stream, 1: min-area axis per node (AxisRng)
 
     bool hit(const Ray& ray, double t_min, double t_max, HitRecord& out) const {  // scene.rs:31-38
         counters().rays++;

@@ -12,7 +12,7 @@
 //   object sphere CX CY CZ R MAT | object moving_sphere C0x3 C1x3 T0 T1 R MAT | object aarect X0 X1 Y0 Y1 Z MAT
 //   object triangle MESH TRI | object transformed XFORM CHILD | object bvh T0 T1 N CHILD...
 //   scene_objects N ID... | lights N ID... | camera FROMx3 ATx3 UPx3 VFOV ASPECT APERTURE FOCUS T0 T1
-//   background black|sky | build_bvh 0|1 | bvh_seed S | end
+//   background black|sky | build_bvh 0|1 | bvh_seed S | bvh_axis_mode 0|1 (after bvh_seed, before the first bvh object) | end
 #pragma once
 #include "orc_render.hpp"
 #include <cstdlib>
@@ -123,7 +123,7 @@ inline std::unique_ptr<Scene> load_scene_desc(const char* text, size_t len) {
                 uint64_t n = tk.u();
                 std::vector<Hittable*> kids(n);
                 for (uint64_t i = 0; i < n; ++i) kids[i] = obj(tk.u());
-                AxisRng ar(sc->bvh_seed);
+                AxisRng ar(sc->bvh_seed, sc->bvh_axis_mode);
                 b->build(kids.data(), kids.size(), t0, t1, ar);
                 h = std::move(b);
             } else throw std::runtime_error("rtscene: object kind " + k);
@@ -148,11 +148,12 @@ inline std::unique_ptr<Scene> load_scene_desc(const char* text, size_t len) {
             sc->background = (k == "sky") ? BG_SKY : BG_BLACK;
         } else if (w == "build_bvh") { build_bvh = tk.u() != 0; }
         else if (w == "bvh_seed") { sc->bvh_seed = tk.u(); }
+        else if (w == "bvh_axis_mode") { uint64_t m = tk.u(); if (m > 1) throw std::runtime_error("rtscene: unknown bvh_axis_mode"); sc->bvh_axis_mode = (uint32_t)m; }
         else throw std::runtime_error("rtscene: unknown record " + w);
     }
     if (build_bvh) {  // scene.rs:106-113
         sc->bvh = std::make_unique<BVHNode>();
-        AxisRng ar(sc->bvh_seed);
+        AxisRng ar(sc->bvh_seed, sc->bvh_axis_mode);
         sc->bvh->build(sc->objects.data(), sc->objects.size(), 0.0, 0.0, ar);
     }
     return sc;

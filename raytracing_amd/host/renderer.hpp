@@ -206,10 +206,18 @@ struct Transformed : Hittable {
 // Split-axis source.  bvh.rs:53 draws `thread_rng().gen_range(0..=2)`; here every BVH build starts a
 // fresh splitmix64 stream from the process-wide seed below, axis = (next >> 33) % 3, one draw per
 // node with >= 3 objects, in construction (pre-) order.
+//
+// Because that RNG is unseeded, EVERY assignment of axes to nodes is a tree the reference can build (each with probability 3^-nodes),
+// and its `hit` results on any of them are "the reference's".  Axis mode 1 (BVH_AXIS_MIN_AREA) uses that freedom: at each node it takes,
+// of the three axes bvh.rs:53 can draw, the one whose median split (the reference's own: stable sort by box minimum, cut at len/2)
+// has the smallest  area(left box)*|left| + area(right box)*|right|,  lowest axis on ties, no draws.  Everything else -- the sort key,
+// the cut, the boxes, the traversal -- stays bvh.rs.  The pagoda walks 25 % fewer records per ray on such a tree.
 inline uint64_t& bvh_axis_seed() { static uint64_t s = 0; return s; }
+enum : uint32_t { BVH_AXIS_SEEDED = 0, BVH_AXIS_MIN_AREA = 1 };
+inline uint32_t& bvh_axis_mode() { static uint32_t m = BVH_AXIS_SEEDED; return m; }
 struct AxisStream {
-    uint64_t state;
-    explicit AxisStream(uint64_t seed) : state(seed) {}
+    uint64_t state; uint32_t mode;
+    explicit AxisStream(uint64_t seed, uint32_t mode_ = BVH_AXIS_SEEDED) : state(seed), mode(mode_) {}
     uint32_t gen_axis() {
         state += 0x9E3779B97F4A7C15ull;
         uint64_t z = state;
@@ -226,6 +234,7 @@ struct BVHNode : Hittable {
     HittableList source;         // root only: the slice handed to new_ (kept for describe())
     double time_0 = 0, time_1 = 0;
     uint64_t axis_seed = 0;      // root only
+    uint32_t axis_mode = 0;      // root only
 
     static BVHNode from_mesh(std::vector<Triangle> triangles, double time_0, double time_1) {  // bvh.rs:27-34
         HittableList h;
@@ -234,9 +243,9 @@ struct BVHNode : Hittable {
         return new_(h, time_0, time_1);
     }
     static BVHNode new_(const HittableList& hittables, double time_0, double time_1) {  // bvh.rs:36-87
-        AxisStream axes(bvh_axis_seed());
+        AxisStream axes(bvh_axis_seed(), bvh_axis_mode());
         BVHNode n = build(hittables.data(), hittables.size(), time_0, time_1, axes);
-        n.source = hittables; n.time_0 = time_0; n.time_1 = time_1; n.axis_seed = bvh_axis_seed();
+        n.source = hittables; n.time_0 = time_0; n.time_1 = time_1; n.axis_seed = bvh_axis_seed(); n.axis_mode = bvh_axis_mode();
         return n;
     }
     std::optional<AABB> bounding_box(double, double) const override { return bbox; }
@@ -252,14 +261,34 @@ struct BVHNode : Hittable {
             node.bbox = *b;
             return node;
         }
-        const uint32_t sort_axis = axes.gen_axis();
-        std::vector<std::pair<double, size_t>> order(len);
+        std::vector<AABB> boxes(len);
         for (size_t i = 0; i < len; ++i) {
             auto b = h[i]->bounding_box(time_0, time_1);
             if (!b) throw std::runtime_error("BVHNode::new: object without a bounding box");
-            order[i] = {b->min[sort_axis], i};
+            boxes[i] = *b;
         }
-        std::stable_sort(order.begin(), order.end(), [](const auto& a, const auto& b) { return a.first < b.first; });  // sort_by is stable
+        std::vector<std::pair<double, size_t>> order(len);
+        auto sort_by = [&](uint32_t axis) {
+            for (size_t i = 0; i < len; ++i) order[i] = {boxes[i].min[axis], i};
+            std::stable_sort(order.begin(), order.end(), [](const auto& a, const auto& b) { return a.first < b.first; });  // sort_by is stable
+        };
+        uint32_t sort_axis = 0;
+        if (axes.mode == BVH_AXIS_SEEDED) sort_axis = axes.gen_axis();
+        else {   // BVH_AXIS_MIN_AREA: the cheapest of the three median splits the reference could draw
+            auto half_cost = [&](size_t b, size_t e) {
+                DVec3 lo = boxes[order[b].second].min, hi = boxes[order[b].second].max;
+                for (size_t i = b + 1; i < e; ++i) { lo = lo.min(boxes[order[i].second].min); hi = hi.max(boxes[order[i].second].max); }
+                const DVec3 d = hi - lo;
+                return (d.x * d.y + d.y * d.z + d.z * d.x) * (double)(e - b);
+            };
+            double best = 0.0;
+            for (uint32_t axis = 0; axis < 3; ++axis) {
+                sort_by(axis);
+                const double c = half_cost(0, len / 2) + half_cost(len / 2, len);
+                if (axis == 0 || c < best) { best = c; sort_axis = axis; }
+            }
+        }
+        sort_by(sort_axis);
         HittableList objects(len);
         for (size_t i = 0; i < len; ++i) objects[i] = h[order[i].second];
         const size_t midpoint = len / 2;

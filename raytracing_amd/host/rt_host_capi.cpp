@@ -18,6 +18,7 @@ extern "C" {
 
 const char* rth_last_error(void) { return g_err.c_str(); }
 void rth_set_bvh_axis_seed(uint64_t seed) { bvh_axis_seed() = seed; }
+int rth_set_bvh_axis_mode(uint32_t mode) { if (mode > BVH_AXIS_MIN_AREA) return -1; bvh_axis_mode() = mode; return 0; }
 
 rth_scene* rth_scene_builtin(const char* name, const char* assets_dir, int legacy_bvh) {
     RTH_TRY

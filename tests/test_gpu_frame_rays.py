@@ -13,9 +13,10 @@ pytestmark = pytest.mark.gpu
 W, H, DEPTH = 1920, 1080, 5
 
 
-@pytest.fixture(scope="module")
-def pagoda(gpu_ctx):
-    hs = rt.HostScene.builtin("mesh", bvh_seed=3)
+# both axis sources: the seeded stream of the parity suites and the min-area tree the bench renders (include/rt_host.h)
+@pytest.fixture(scope="module", params=["seeded", "min_area"])
+def pagoda(gpu_ctx, request):
+    hs = rt.HostScene.builtin("mesh", bvh_seed=3, bvh_axis=request.param)
     gs = gpu_ctx.upload(hs)
     yield gs, orc.OracleScene(hs.describe())
     gs.close()

@@ -23,8 +23,13 @@ SCENES = [  # (name, legacy_bvh, width, height) -- sizes keep the oracle (1 ms/r
 ]
 
 
-def _pair(name, legacy_bvh, seed=5):
-    hs = rt.HostScene.builtin(name, bvh_seed=seed, legacy_bvh=legacy_bvh)
+SCENES = [c + ("seeded",) for c in SCENES] + [   # the min-area axis choice (include/rt_host.h): another tree of the reference's distribution
+    ("mesh", False, 64, 36, "min_area"), ("random", False, 128, 72, "min_area"), ("random_blur", False, 64, 36, "min_area"),
+    ("cornell", True, 96, 54, "min_area"), ("simple_triangle", True, 96, 54, "min_area")]
+
+
+def _pair(name, legacy_bvh, seed=5, axis="seeded"):
+    hs = rt.HostScene.builtin(name, bvh_seed=seed, legacy_bvh=legacy_bvh, bvh_axis=axis)
     return hs, orc.OracleScene(hs.describe())
 
 
@@ -36,9 +41,9 @@ def _assert_same_hits(g, o):
     assert np.array_equal(gt.view(np.uint64), ot.view(np.uint64)), f"{(gt.view(np.uint64) != ot.view(np.uint64)).sum()} t values differ in bits"
 
 
-@pytest.mark.parametrize("name,legacy_bvh,w,h", SCENES)
-def test_primary_hits_bit_exact(gpu_ctx, name, legacy_bvh, w, h):
-    hs, osc = _pair(name, legacy_bvh)
+@pytest.mark.parametrize("name,legacy_bvh,w,h,axis", SCENES)
+def test_primary_hits_bit_exact(gpu_ctx, name, legacy_bvh, w, h, axis):
+    hs, osc = _pair(name, legacy_bvh, axis=axis)
     gs = gpu_ctx.upload(hs)
     rays = osc.primary_rays(w, h, 0, 0x5EED)
     g = gs.trace_closest(rays, 0.001, 100000.0, counters=True)
@@ -54,10 +59,11 @@ def test_primary_hits_bit_exact(gpu_ctx, name, legacy_bvh, w, h):
     gs.close()
 
 
-@pytest.mark.parametrize("name,legacy_bvh", [("random", False), ("cornell", False), ("mesh", False), ("simple", False)])
-def test_incoherent_rays_bit_exact(gpu_ctx, name, legacy_bvh):
+@pytest.mark.parametrize("name,legacy_bvh,axis", [("random", False, "seeded"), ("cornell", False, "seeded"), ("mesh", False, "seeded"), ("simple", False, "seeded"),
+                                                  ("random", False, "min_area"), ("cornell", False, "min_area"), ("mesh", False, "min_area")])
+def test_incoherent_rays_bit_exact(gpu_ctx, name, legacy_bvh, axis):
     # bounce-like rays: random origins near the scene, random (un-normalised) directions, shadow-ray window
-    hs, osc = _pair(name, legacy_bvh, seed=11)
+    hs, osc = _pair(name, legacy_bvh, seed=11, axis=axis)
     gs = gpu_ctx.upload(hs)
     rng = np.random.default_rng(7)
     n = 1500 if name == "mesh" else 6000

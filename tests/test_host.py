@@ -53,11 +53,12 @@ def _obj_of(prims, p):
     return int(q["inst_id"]) if q["inst_id"] != rt.NONE else int(q["object_id"])
 
 
-@pytest.mark.parametrize("name,seed", [("random", 1), ("random", 7), ("mesh", 3), ("single_sphere_light", 2)])
-def test_host_bvh_equals_oracle_bvh(name, seed):
-    # bvh.rs:36-87 built twice, independently (host library vs oracle), from the same axis stream:
-    # same pre-order node boxes (bitwise) and the same leaf objects
-    hs = rt.HostScene.builtin(name, bvh_seed=seed)
+@pytest.mark.parametrize("name,seed,axis", [("random", 1, "seeded"), ("random", 7, "seeded"), ("mesh", 3, "seeded"), ("single_sphere_light", 2, "seeded"),
+                                            ("random", 1, "min_area"), ("mesh", 3, "min_area"), ("random_blur", 2, "min_area")])
+def test_host_bvh_equals_oracle_bvh(name, seed, axis):
+    # bvh.rs:36-87 built twice, independently (host library vs oracle), from the same axis source (the seeded stream, or the
+    # min-area choice among the three axes bvh.rs:53 can draw): same pre-order node boxes (bitwise) and the same leaf objects
+    hs = rt.HostScene.builtin(name, bvh_seed=seed, bvh_axis=axis)
     osc = orc.OracleScene(hs.describe())
     boxes, kids = osc.bvh_dump()
     h = hs.header(); n = hs.nodes()[:h.root_end]; pr = hs.prims()
@@ -72,9 +73,60 @@ def test_host_bvh_equals_oracle_bvh(name, seed):
             assert l == kl and (r == kr or (r is None and kl == kr and n[i]["flags"] & 2))
 
 
-def test_instance_sub_bvhs_equal_oracle():
+def _median_split_tree(boxes, ids, pick_axis):
+    """bvh.rs:36-87 in numpy over object boxes [n,6]: returns the pre-order list of node boxes; `pick_axis(boxes, ids)` is the RNG."""
+    out = []
+    def rec(ids):
+        at = len(out); out.append(None)
+        if len(ids) > 2:
+            order = ids[np.argsort(boxes[ids, pick_axis(boxes, ids)], kind="stable")]
+            mid = len(order) // 2
+            rec(order[:mid]); rec(order[mid:])
+        out[at] = np.concatenate([boxes[ids, :3].min(axis=0), boxes[ids, 3:].max(axis=0)])
+    rec(ids)
+    return np.array(out)
+
+
+def test_min_area_tree_is_a_tree_the_reference_can_draw():
+    # the min-area mode only chooses WHICH of bvh.rs:53's three possible draws a node takes: feeding those choices, as an axis
+    # sequence, to a plain restatement of bvh.rs:36-87 gives the same tree; and its area cost is below the seeded stream's
+    hs = rt.HostScene.builtin("random", bvh_seed=1, bvh_axis="min_area")
+    h = hs.header(); n = hs.nodes()[:h.root_end]
+    text = hs.describe().decode()
+    osc = orc.OracleScene(text)
+    boxes, kids = osc.bvh_dump()
+    assert np.array_equal(boxes[:, :3], n["bmin"]) and np.array_equal(boxes[:, 3:], n["bmax"])
+    line = next(l for l in text.splitlines() if l.startswith("scene_objects"))
+    obj_ids = [int(x) for x in line.split()[2:]]
+    ob = np.array([osc.object_bbox(i) for i in obj_ids])      # the objects' own boxes (shape.rs bounding_box), by position in the list
+    ids = np.arange(len(obj_ids))
+
+    def half_cost(b, sel):
+        d = b[sel, 3:].max(axis=0) - b[sel, :3].min(axis=0)
+        return (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]) * len(sel)
+
+    def min_area(b, sel):
+        costs = []
+        for a in range(3):
+            o = sel[np.argsort(b[sel, a], kind="stable")]
+            costs.append(half_cost(b, o[:len(o) // 2]) + half_cost(b, o[len(o) // 2:]))
+        return int(np.argmin(costs))          # first minimum = lowest axis on ties
+
+    mine = _median_split_tree(ob, ids, min_area)
+    assert np.array_equal(mine, boxes)
+    seeded = rt.HostScene.builtin("random", bvh_seed=1)
+    ns = seeded.nodes()[:seeded.header().root_end]
+    def area(q):   # summed half-area of the nodes that do not hold the 1000-unit ground sphere
+        d = q["bmax"] - q["bmin"]
+        d = d[d.max(axis=1) < 100.0]
+        return float((d[:, 0] * d[:, 1] + d[:, 1] * d[:, 2] + d[:, 2] * d[:, 0]).sum())
+    assert area(n) < 0.95 * area(ns)
+
+
+@pytest.mark.parametrize("axis", ["seeded", "min_area"])
+def test_instance_sub_bvhs_equal_oracle(axis):
     # cornell: Transformed(BVHNode::from_mesh(cube)) x6 over 4 distinct cube BVHs (main.rs:117-188)
-    hs = rt.HostScene.builtin("cornell", bvh_seed=4)
+    hs = rt.HostScene.builtin("cornell", bvh_seed=4, bvh_axis=axis)
     osc = orc.OracleScene(hs.describe())
     h = hs.header(); nodes = hs.nodes(); pr = hs.prims()
     inst = [p for p in pr if p["kind"] == 4]

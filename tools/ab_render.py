@@ -10,7 +10,7 @@ spp = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 flags = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 scene, legacy, W, H, integ, depth = WORKLOADS[wl]
-ctx = rt.Context(0); gs = ctx.upload(rt.HostScene.builtin(scene, bvh_seed=3, legacy_bvh=legacy))
+ctx = rt.Context(0); gs = ctx.upload(rt.HostScene.builtin(scene, bvh_seed=3, legacy_bvh=legacy, bvh_axis=os.environ.get("RT_BVH_AXIS", "min_area")))
 acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda"); torch.cuda.synchronize()
 for r in range(reps + 1):
     acc.zero_(); torch.cuda.synchronize()

@@ -5,7 +5,7 @@ import torch
 import raytracing_amd as rt
 name, integ = (sys.argv[1] if len(sys.argv) > 1 else "mesh"), int(sys.argv[2]) if len(sys.argv) > 2 else rt.INT_BRDF
 W, H = (1920, 1080) if name != "random" else (400, 225)
-ctx = rt.Context(0); gs = ctx.upload(rt.HostScene.builtin(name, bvh_seed=3))
+ctx = rt.Context(0); gs = ctx.upload(rt.HostScene.builtin(name, bvh_seed=3, bvh_axis=os.environ.get("RT_BVH_AXIS", "min_area")))
 acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda"); torch.cuda.synchronize()
 st = gs.render(acc.data_ptr(), W, H, 0, 4 if name != "random" else 64, 5 if name != "random" else 50, integ).as_dict()
 print(st)

@@ -2,7 +2,7 @@
 one-lane pass of the bench workload (dispatch order: path rays, shadow rays, path rays, ...), HBM-side traffic
 (FETCH_SIZE doubled: gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md "HBM"; both in KiB) and issue utilisation.
 usage: pmc_collect.py <gpurun_out prefix> <workload> <spp per pass> <stats json of the profiled render> <kernel-trace dir>"""
-import csv, glob, json, sys, collections
+import os, csv, glob, json, sys, collections
 
 prefix, workload, spp, stats_path, kt_dir = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5]
 st = json.load(open(stats_path))
@@ -26,7 +26,7 @@ def durations(kernel):
     return [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
 
 
-out = {"workload": workload, "spp_per_step": spp, "render_stats": st,
+out = {"workload": workload, "bvh_axis": os.environ.get("RT_BVH_AXIS", "min_area"), "spp_per_step": spp, "render_stats": st,
        "source": "tools/profile_round.sh: one rt_render of one pass on ONE lane per counter pass (counter collection serialises dispatches)"}
 for kernel, key in (("k_trace", "k_trace"), ("k_shade", "k_shade")):
     f, w, a, b = dispatches("f", kernel), dispatches("w", kernel), dispatches("a", kernel), dispatches("b", kernel)

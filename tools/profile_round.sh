@@ -11,7 +11,7 @@ o=gpurun_out/$tag
 mkdir -p gpurun_out
 timeout -k 10 400 python3 bench.py --workload $wl > ${o}_bench.json 2> ${o}_bench.err || exit 1
 spass=$(python3 -c "import json,sys; print(json.loads(open('${o}_bench.json').read().strip().splitlines()[-1])['samples_per_pass'])") || exit 1
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d ${o}_kt -- python3 bench.py --workload $wl --no-cpu-baseline > ${o}_bench_under_rocprof.json 2> ${o}_kt.log || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d ${o}_kt -- python3 bench.py --workload $wl --no-cpu-baseline --no-seeded-compare > ${o}_bench_under_rocprof.json 2> ${o}_kt.log || exit 1
 cp "$(ls -t ${o}_kt/*/*kernel_stats.csv | head -1)" ${o}_bench_kernel_stats.csv || exit 1
 R="python3 tools/render_once.py mesh $integ $spass 5"
 timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d ${o}_kt1 -- $R > ${o}_pass_stats.txt 2> ${o}_kt1.log || exit 1

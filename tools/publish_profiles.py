@@ -12,6 +12,7 @@ pm = json.load(open(os.path.join(src, f"{tag}_pmc.json")))
 latest = {k: pm[k] for k in ("workload", "spp_per_step", "hbm_bytes_per_launch", "measured_hbm_frac", "valu_issue_utilisation", "scalar_issue_utilisation",
                              "valu_insts_per_ray", "hbm_bytes_per_ray")}
 latest["k_trace_launches"] = pm["k_trace"]["n"]
+latest["bvh_axis"] = pm.get("bvh_axis", "seeded")
 latest["source"] = f"profiles/{tag}_pmc.json (rocprofv3 --pmc, one pass of {pm['spp_per_step']} spp on one lane: FETCH_SIZE x2 + WRITE_SIZE, SQ_INSTS_*, GRBM_GUI_ACTIVE)"
 diag = os.path.join(src, f"{tag}_diag.txt")
 if os.path.exists(diag):

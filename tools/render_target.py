@@ -10,7 +10,7 @@ out = sys.argv[1]
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 per_call = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 W, H, depth = 1920, 1080, 5
-hs = rt.HostScene.builtin("mesh", bvh_seed=3)
+hs = rt.HostScene.builtin("mesh", bvh_seed=3, bvh_axis=os.environ.get("RT_BVH_AXIS", "min_area"))
 ctx = rt.Context(0); gs = ctx.upload(hs)
 acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda"); torch.cuda.synchronize()
 gs.render(acc.data_ptr(), W, H, 0, per_call, depth, rt.INT_MIS)   # warm-up (buffers)
