@@ -93,7 +93,7 @@ struct LaneCount {
     uint32_t wsteps;  // records this wave stepped through (wave-uniform; summed into stats[15])
     uint32_t pruned_until, uncertified;  // COUNT variant only: end of the subtree strict pruning would have skipped; ray walked without certificate
 #ifdef RT_TRACE_DIAG  // diagnostic build only (make diag): wave-level step counts and s_memtime cycle stamps
-    uint64_t steps, leaf_steps, cyc_wait, cyc_total, lane_steps, exact_box, exact_tri;
+    uint64_t steps, leaf_steps, cyc_wait, cyc_total, lane_steps, exact_box, exact_tri, cyc_xbox, cyc_xtri, cyc_setup, cyc_leaf, leaf_open;
     uint32_t diag_flags;  // bit 0: top-level walk in the NaN-capable (literal) mode, bit 1: ray not certified for pruning, bit 2: fp32 range guard failed
 #endif
 };
@@ -619,6 +619,9 @@ RT_DEV lanemask box_step(const Window& w, const BoxFilter& bf, const PruneState&
         box_filter<B>(bf, w, cp, cf);
         m_pass = m_act & cp & ~sp_apply;
         if (COUNT || (m_act & ~(cp | cf | sp_apply)) != 0ull) {  // rare: a plane value within the error bound of best / t_min
+#ifdef RT_TRACE_DIAG
+            const uint64_t cx0 = __builtin_readcyclecounter();
+#endif
             const RayS ray = src.get();
             const bool act = mask_lane(m_act);
             const bool ex = act & box_exact<true>(nodes, rec, ray.o, src.inv(), t_min, h.best);
@@ -628,7 +631,7 @@ RT_DEV lanemask box_step(const Window& w, const BoxFilter& bf, const PruneState&
             }
             m_pass = __builtin_amdgcn_ballot_w64(ex) & ~sp_apply;
 #ifdef RT_TRACE_DIAG
-            cnt.exact_box += 1;
+            cnt.exact_box += 1; cnt.cyc_xbox += __builtin_readcyclecounter() - cx0;
 #endif
         }
     } else {
@@ -646,6 +649,9 @@ RT_DEV bool tri2_exact(const SceneDev& sc, uint32_t node, uint32_t rec_off, lane
                        double t_min, uint32_t inst_prim, BoxFilter& bf, LaneCount& cnt) {
     cptr<rt_node> nodes = as_const(sc.nodes);
     cptr<rt_geom> geom = as_const(sc.geom);
+#ifdef RT_TRACE_DIAG
+    const uint64_t ct0 = __builtin_readcyclecounter();
+#endif
     const RayS ray = src.get();
     d3 xo, xd;
     apply_xform(sc, cur_xf, ray, xo, xd);
@@ -671,7 +677,7 @@ RT_DEV bool tri2_exact(const SceneDev& sc, uint32_t node, uint32_t rec_off, lane
     }
     if (MODE == BOX_PLAIN && changed) box_filter_set_best(bf, h.best);
 #ifdef RT_TRACE_DIAG
-    cnt.exact_tri += 1;
+    cnt.exact_tri += 1; cnt.cyc_xtri += __builtin_readcyclecounter() - ct0;
 #endif
     return changed;
 }
@@ -766,6 +772,9 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
             cnt.wsteps += 1u;
 #ifdef RT_TRACE_DIAG
             cnt.cyc_wait += __builtin_readcyclecounter() - c0; cnt.steps += 1; cnt.leaf_steps += (rec & RT_STREAM_KIND) ? 1u : 0u;
+            if (cnt.cyc_setup == 0) cnt.cyc_setup = c0 - cnt.cyc_total;   // kernel entry (cyc_total holds the start stamp) to the first record
+            if (cnt.leaf_open) cnt.cyc_leaf += c0 - cnt.leaf_open;
+            cnt.leaf_open = (rec & RT_STREAM_KIND) ? c0 : 0;
 #endif
             if (RT_LEAF_FIRST && MODE == BOX_PLAIN && !COUNT && (rec & RT_STREAM_KIND) == RT_STREAM_TRI2 && wword<8>(w) == cur_xf) {
                 // Common leaf, rays already in its space: triangle filter FIRST.  The leaf's box only gates its own
@@ -944,7 +953,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : 
     h.best = t_max; h.prim = RT_NONE; h.inst = RT_NONE;
     LaneCount cnt; cnt.box = cnt.tri = cnt.sph = cnt.bad = 0; cnt.pruned_until = 0; cnt.uncertified = 0; cnt.wsteps = 0;
 #ifdef RT_TRACE_DIAG
-    cnt.steps = cnt.leaf_steps = cnt.cyc_wait = cnt.lane_steps = cnt.exact_box = cnt.exact_tri = 0; cnt.cyc_total = __builtin_readcyclecounter(); cnt.diag_flags = 0;
+    cnt.steps = cnt.leaf_steps = cnt.cyc_wait = cnt.lane_steps = cnt.exact_box = cnt.exact_tri = 0; cnt.cyc_xbox = cnt.cyc_xtri = cnt.cyc_setup = cnt.cyc_leaf = cnt.leaf_open = 0; cnt.cyc_total = __builtin_readcyclecounter(); cnt.diag_flags = 0;
 #endif
     if (REGS) {
         LaneHitRegs hr; hr.best = t_max; hr.prim = RT_NONE; hr.inst = RT_NONE;
@@ -968,6 +977,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : 
         atomicAdd(&stats[12], (unsigned long long)cnt.exact_tri);
         atomicAdd(&stats[4], (unsigned long long)cnt.steps); atomicAdd(&stats[5], (unsigned long long)cnt.leaf_steps);
         atomicAdd(&stats[6], (unsigned long long)cnt.cyc_wait); atomicAdd(&stats[7], (unsigned long long)cnt.cyc_total); atomicAdd(&stats[8], 1ull);
+        if (!COUNT) {   // cycle shares (the counting kernel uses these slots for its test counts)
+            atomicAdd(&stats[13], (unsigned long long)cnt.cyc_xtri); atomicAdd(&stats[14], (unsigned long long)cnt.cyc_xbox);
+            atomicAdd(&stats[1], (unsigned long long)cnt.cyc_setup); atomicAdd(&stats[2], (unsigned long long)cnt.cyc_leaf);
+        }
     }
 #endif
     if (stats && lane_id() == 0) atomicAdd(&stats[15], (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)cnt.wsteps));
@@ -1970,8 +1983,9 @@ static void launch_trace(rt_scene* sc, unsigned long long* lstats, uint32_t lcap
         for (int k = 0; k < 16; ++k) if (k != 10) d[k] -= d0[k];
         (void)hipMemsetAsync(lstats + 10, 0, sizeof(unsigned long long), st);
         const double w = (double)std::max(d[8], 1ull);
-        fprintf(stderr, "[diag] rays %llu waves %llu  steps/wave %.0f  leaf steps/wave %.0f  lane use %.1f%%  cycles/wave %.0f  cycles/step %.0f  wait/step %.0f  max steps %llu  exact box steps/wave %.1f  exact tri steps/wave %.1f\n",
-                d[0], d[8], d[4] / w, d[5] / w, 100.0 * d[9] / (64.0 * std::max(d[4], 1ull)), d[7] / w, (double)d[7] / std::max(d[4], 1ull), (double)d[6] / std::max(d[4], 1ull), d[10], d[11] / w, d[12] / w);
+        fprintf(stderr, "[diag] rays %llu waves %llu  steps/wave %.0f  leaf steps/wave %.0f  lane use %.1f%%  cycles/wave %.0f  cycles/step %.0f  wait/step %.0f  max steps %llu  exact box steps/wave %.1f  exact tri steps/wave %.1f  | of a wave's cycles: set-up %.1f%%  leaf steps %.1f%% (exact tri blocks %.1f%%)  exact box blocks %.1f%%  scalar-load wait %.1f%%\n",
+                d[0], d[8], d[4] / w, d[5] / w, 100.0 * d[9] / (64.0 * std::max(d[4], 1ull)), d[7] / w, (double)d[7] / std::max(d[4], 1ull), (double)d[6] / std::max(d[4], 1ull), d[10], d[11] / w, d[12] / w,
+                100.0 * d[1] / std::max(d[7], 1ull), 100.0 * d[2] / std::max(d[7], 1ull), 100.0 * d[13] / std::max(d[7], 1ull), 100.0 * d[14] / std::max(d[7], 1ull), 100.0 * d[6] / std::max(d[7], 1ull));
     }
 #endif
 }
