@@ -40,6 +40,7 @@ pub const RT_RENDER_NO_SORT: u32 = 2;
 pub const RT_RENDER_ONE_LANE: u32 = 4;
 pub const RT_RENDER_LANE_WALK: u32 = 8;
 pub const RT_RENDER_MATERIAL_BINS: u32 = 16;
+pub const RT_RENDER_COUNT_STEPS: u32 = 32;
 
 #[repr(C)]
 #[derive(Clone, Copy, Default)]

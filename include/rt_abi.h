@@ -172,6 +172,9 @@ typedef struct rt_render_params {
 #define RT_RENDER_LANE_WALK 8u   /* A-B: trace secondary and shadow rays with the per-lane walk (k_walk: own cursor and vector loads per lane, finished
                                   * lanes take the next ray) in scenes that qualify (a pruned space, no instances); same frame, measured slower than the
                                   * default wave-coherent walk */
+#define RT_RENDER_COUNT_STEPS 32u   /* fill rt_stats.trace_wave_steps (record steps of the traversal waves: what bench.py's byte model needs).  One
+                                        same-address atomic per wave: measured 5 % of the frame, so a plain render leaves the field 0.
+                                        (RT_RENDER_COUNT_TESTS implies it.) */
 #define RT_RENDER_MATERIAL_BINS 16u /* opt-in: before every shade launch regroup the queue's slots by the material class of their hits
                                         (stable, atomic-free partition: k_bin_count / k_bin_scan / k_bin_scatter), so that a wave shades
                                         one class.  Frames are bit-identical either way.  Measured r02: +1.5 % on `random` (three

@@ -983,7 +983,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : 
         }
     }
 #endif
-    if (stats && lane_id() == 0) atomicAdd(&stats[15], (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)cnt.wsteps));
+    if (sc.count_steps != 0u && stats && lane_id() == 0) atomicAdd(&stats[15], (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)cnt.wsteps));
     if (valid) {
         const uint32_t hp = h.prim;
         const double ht = hp != RT_NONE ? (double)h.best : __builtin_nan("");
@@ -1456,6 +1456,12 @@ RT_DEV void push_queue_keyed(bool want, uint32_t path, uint32_t key, uint32_t* _
     }
 }
 
+// k_shade extends its two queues with ONE atomic per block and queue (after RT_SHADE_TILES tiles of 256 slots), not one per wave: the
+// counters are single addresses, and device-scope atomics on one address from 8 XCDs serialise at several ns each -- 6 M of them per
+// 50-spp pass were a third of k_shade's time (r02g: one per 256 slots 1 837 -> 1 965 Mrays/s, same frame).
+#ifndef RT_SHADE_TILES
+#define RT_SHADE_TILES 1u   /* measured: 1 tile 1 955, 4 tiles 1 908, 8 tiles 1 909 Mrays/s (per-wave atomics: 1 838) */
+#endif
 RT_DEV void push_queue(bool want, uint32_t path, uint32_t* __restrict__ queue, uint32_t* __restrict__ count) {
     const uint64_t m = __ballot(want);
     if (m == 0ull) return;
@@ -1551,10 +1557,18 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, PathBuffers pb, cons
                                                uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_keys, uint32_t* __restrict__ next_count,
                                                uint32_t* __restrict__ shadow_queue, uint32_t* __restrict__ shadow_keys, uint32_t* __restrict__ shadow_count) {
     const uint32_t n = *n_ptr;
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if ((gid & ~63u) >= n) return;
-    const bool valid = gid < n;
+    // A block shades RT_SHADE_TILES tiles of 256 queue slots one after the other and parks what each thread wants to push in LDS; the
+    // queues are then extended with ONE atomic per block and queue (push_tiles_block).  Whole blocks leave together: every wave of a
+    // live block takes part in the barriers.
+    const uint32_t block_first = blockIdx.x * (256u * RT_SHADE_TILES);
+    if (block_first >= n) return;
+    __shared__ uint32_t st_path[RT_SHADE_TILES][256], st_nkey[RT_SHADE_TILES][256], st_skey[RT_SHADE_TILES][256];
+    __shared__ uint8_t st_flag[RT_SHADE_TILES][256];
     const uint32_t cap = pb.cap;
+#pragma unroll 1
+    for (uint32_t tile = 0; tile < RT_SHADE_TILES; ++tile) {
+    const uint32_t gid = block_first + tile * 256u + threadIdx.x;
+    const bool valid = gid < n;
     bool want_next = false, want_shadow = false;
     uint32_t path = 0, next_key = 0, shadow_key = 0;
     if (valid) {
@@ -1697,8 +1711,39 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, PathBuffers pb, cons
         if (want_sig) pb.sig[path] += sg;
         if (done) { pb.terminal[(size_t)path * 4u + 0] = terminal.x; pb.terminal[(size_t)path * 4u + 1] = terminal.y; pb.terminal[(size_t)path * 4u + 2] = terminal.z; }
     }
-    push_queue_keyed(want_next, path, next_key, next_queue, next_keys, next_count);
-    push_queue_keyed(want_shadow, path, shadow_key, shadow_queue, shadow_keys, shadow_count);
+    st_path[tile][threadIdx.x] = path; st_nkey[tile][threadIdx.x] = next_key; st_skey[tile][threadIdx.x] = shadow_key;
+    st_flag[tile][threadIdx.x] = (uint8_t)((want_next ? 1u : 0u) | (want_shadow ? 2u : 0u));
+    }
+    // every thread reads back only what it parked itself: no barrier needed before this point
+    __shared__ uint32_t cnt_s[2][RT_SHADE_TILES * 4u], base_s[2];
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+#pragma unroll
+    for (uint32_t tile = 0; tile < RT_SHADE_TILES; ++tile) {
+        const uint32_t fl = st_flag[tile][threadIdx.x];
+        const uint64_t ma = __ballot((fl & 1u) != 0u), mb = __ballot((fl & 2u) != 0u);
+        if (lane == 0u) { cnt_s[0][tile * 4u + wv] = (uint32_t)__popcll(ma); cnt_s[1][tile * 4u + wv] = (uint32_t)__popcll(mb); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2u) {
+        uint32_t tot = 0u;
+        for (uint32_t k = 0; k < RT_SHADE_TILES * 4u; ++k) tot += cnt_s[threadIdx.x][k];
+        base_s[threadIdx.x] = tot ? atomicAdd(threadIdx.x == 0u ? next_count : shadow_count, tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t ra = base_s[0], rb = base_s[1];   // running bases over (tile, wave) in that order
+#pragma unroll
+    for (uint32_t tile = 0; tile < RT_SHADE_TILES; ++tile) {   // slots inside a block: tile, then wave, then lane
+        uint32_t ba = 0u, bb = 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            if (k == wv) { ba = ra; bb = rb; }
+            ra += cnt_s[0][tile * 4u + k]; rb += cnt_s[1][tile * 4u + k];
+        }
+        const uint32_t fl = st_flag[tile][threadIdx.x], path = st_path[tile][threadIdx.x];
+        const uint64_t ma = __ballot((fl & 1u) != 0u), mb = __ballot((fl & 2u) != 0u);
+        if (fl & 1u) { const uint32_t sl = ba + (uint32_t)__popcll(ma & ((1ull << lane) - 1ull)); next_queue[sl] = path; if (next_keys) next_keys[sl] = st_nkey[tile][threadIdx.x]; }
+        if (fl & 2u) { const uint32_t sl = bb + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull)); shadow_queue[sl] = path; if (shadow_keys) shadow_keys[sl] = st_skey[tile][threadIdx.x]; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1958,10 +2003,12 @@ enum { CAT_TRACE = 0, CAT_SHADE = 1, CAT_OTHER = 2, CAT_SHADOW = 3, CAT_N = 4 };
 
 static void launch_trace(rt_scene* sc, unsigned long long* lstats, uint32_t lcap, hipStream_t st, bool count, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_bound, const double* rays, double t_min,
                          double t_max, uint32_t* out_prim, uint32_t* out_inst, double* out_t, uint32_t lanes = 64u, uint32_t t_stride = 1u, PathHit* out_hit = nullptr, bool shadow = false,
-                         const uint32_t* remap = nullptr) {
+                         const uint32_t* remap = nullptr, bool count_steps = true) {
     if (n_bound == 0) return;
+    SceneDev dv = sc->dev;   // this launch's copy of the kernel argument
+    dv.count_steps = count_steps ? 1u : 0u;
     const dim3 grid((uint32_t)((((uint64_t)n_bound + lanes - 1u) / lanes + 3u) / 4u));  // waves of `lanes` rays, four waves per block
-#define RT_LAUNCH_TRACE_S(C, I, R, S) hipLaunchKernelGGL((k_trace<C, I, R, S>), grid, dim3(256), 0, st, sc->dev, queue, n_ptr, n_bound, rays, lcap, t_min, t_max, out_prim, out_inst, out_t, lstats, lanes, t_stride, out_hit, remap)
+#define RT_LAUNCH_TRACE_S(C, I, R, S) hipLaunchKernelGGL((k_trace<C, I, R, S>), grid, dim3(256), 0, st, dv, queue, n_ptr, n_bound, rays, lcap, t_min, t_max, out_prim, out_inst, out_t, lstats, lanes, t_stride, out_hit, remap)
 #define RT_LAUNCH_TRACE_R(C, I, R) do { if (shadow && !C) RT_LAUNCH_TRACE_S(C, I, R, !C); else RT_LAUNCH_TRACE_S(C, I, R, false); } while (0)
 #define RT_LAUNCH_TRACE(C, I) do { if (sc->reg_ray) RT_LAUNCH_TRACE_R(C, I, true); else RT_LAUNCH_TRACE_R(C, I, false); } while (0)
     const bool inst = sc->has_instances;  // scenes without BVHNode objects use the kernel variant compiled without the nested walk
@@ -2054,7 +2101,7 @@ static int capture_queue(Workspace& ws, hipStream_t st, const uint32_t* queue, u
 
 static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bool explicit_lists, uint32_t width, uint32_t height, uint32_t sample0, int32_t max_depth,
                      int32_t integrator, uint64_t seed, bool count_tests, bool sort_rays, EventTimer& tm, uint64_t& launches, uint64_t* shadow_rays = nullptr, Capture* cap = nullptr,
-                     bool lane_walk = false, bool want_sig = false, bool bins = false) {
+                     bool lane_walk = false, bool want_sig = false, bool bins = false, bool count_steps = true) {
     PathBuffers pbk = ws.pb;   // what the kernels see: signatures only for rt_sample_radiance_sig
     if (!want_sig) pbk.sig = nullptr;
     else HIP_OK(hipMemsetAsync(pbk.sig, 0, (size_t)n * sizeof(unsigned long long), st));
@@ -2077,7 +2124,7 @@ static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bo
         HIP_OK(hipMemsetAsync(ws.counts + 2, 0, sizeof(uint32_t), st));
         tm.begin(CAT_TRACE);
         if (use_walk && bounce >= 1) { int rc = launch_walk(sc, ws, st, ws.queue[cur], ws.counts + cur, live, ws.pb.rays, 0.001, 100000.0, ws.pb.hit, nullptr, 1u, false); if (rc != RT_OK) return rc; }
-        else launch_trace(sc, ws.stats, ws.cap, st, count_tests, ws.queue[cur], ws.counts + cur, live, ws.pb.rays, 0.001, 100000.0, nullptr, nullptr, nullptr, 64u, 1u, ws.pb.hit);  // integrator.rs:38
+        else launch_trace(sc, ws.stats, ws.cap, st, count_tests, ws.queue[cur], ws.counts + cur, live, ws.pb.rays, 0.001, 100000.0, nullptr, nullptr, nullptr, 64u, 1u, ws.pb.hit, false, nullptr, count_steps);  // integrator.rs:38
         tm.end();
         if (cap && !cap->shadow && (uint32_t)bounce == cap->bounce) return capture_queue(ws, st, ws.queue[cur], live, ws.pb.rays, ws.pb.hit, nullptr, *cap);
         const bool mis_shadow = integrator == RT_INT_MIS && sc->dev.n_lights > 0;
@@ -2100,10 +2147,10 @@ static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bo
         }
         // shade appends survivors (and, when sorting, their coherence keys) compactly to the raw queues
         if (sort_rays)
-            hipLaunchKernelGGL(k_shade, grid_for(live), dim3(256), 0, st, sc->dev, pbk, ws.queue[cur], order, ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
+            hipLaunchKernelGGL(k_shade, dim3((live + 256u * RT_SHADE_TILES - 1u) / (256u * RT_SHADE_TILES)), dim3(256), 0, st, sc->dev, pbk, ws.queue[cur], order, ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
                                seed, ws.raw_queue, ws.raw_keys, ws.counts + nxt, ws.raw_squeue, ws.raw_skeys, ws.counts + 2);
         else
-            hipLaunchKernelGGL(k_shade, grid_for(live), dim3(256), 0, st, sc->dev, pbk, ws.queue[cur], order, ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
+            hipLaunchKernelGGL(k_shade, dim3((live + 256u * RT_SHADE_TILES - 1u) / (256u * RT_SHADE_TILES)), dim3(256), 0, st, sc->dev, pbk, ws.queue[cur], order, ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
                                seed, ws.queue[nxt], (uint32_t*)nullptr, ws.counts + nxt, ws.shadow_queue, (uint32_t*)nullptr, ws.counts + 2);
         HIP_OK(hipMemcpyAsync(ws.h_counts, ws.counts, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
@@ -2122,7 +2169,7 @@ static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bo
             double* t_shadow = ws.pb.records + (size_t)bounce * ws.cap * REC_STRIDE + REC_T_SHADOW;
             if (use_walk) { int rc = launch_walk(sc, ws, st, ws.shadow_queue, ws.counts + 2, shadow_live, ws.pb.shadow_rays, 0.001, 10000.0, nullptr, t_shadow, (uint32_t)REC_STRIDE, true); if (rc != RT_OK) return rc; }
             else launch_trace(sc, ws.stats, ws.cap, st, count_tests, ws.shadow_queue, ws.counts + 2, shadow_live, ws.pb.shadow_rays, 0.001, 10000.0, nullptr, nullptr,
-                              t_shadow, 64u, (uint32_t)REC_STRIDE, nullptr, true);  // integrator.rs:82
+                              t_shadow, 64u, (uint32_t)REC_STRIDE, nullptr, true, nullptr, count_steps);  // integrator.rs:82
             tm.end();
             launches += 1;
             if (cap && cap->shadow && (uint32_t)bounce == cap->bounce)
@@ -3104,7 +3151,7 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
             const uint32_t s0 = p->spp_begin + k * spass;
             const uint32_t ns = std::min(spass, p->spp_end - s0);
             int r = run_paths(sc, ws, L.st, npix * ns, false, p->width, p->height, s0, p->max_depth, p->integrator, p->seed, count_tests, sort_rays, L.tm, L.launches, &L.shadow_rays, nullptr, (p->flags & RT_RENDER_LANE_WALK) != 0, false,
-                              (p->flags & RT_RENDER_MATERIAL_BINS) != 0);
+                              (p->flags & RT_RENDER_MATERIAL_BINS) != 0, (p->flags & (RT_RENDER_COUNT_STEPS | RT_RENDER_COUNT_TESTS)) != 0);
             if (r != RT_OK) return r;
             if (k > 0) {
                 std::unique_lock<std::mutex> lk(mu);
@@ -3195,7 +3242,7 @@ static void job_main(rt_job* J) {
         for (uint32_t s0 = p.spp_begin; s0 < p.spp_end; s0 += J->spass) {
             const uint32_t ns = std::min(J->spass, p.spp_end - s0);
             int r = run_paths(sc, ws, st, npix * ns, false, p.width, p.height, s0, p.max_depth, p.integrator, p.seed, false, sort_rays, tm, launches, &shadow_rays, nullptr,
-                              (p.flags & RT_RENDER_LANE_WALK) != 0, false, (p.flags & RT_RENDER_MATERIAL_BINS) != 0);
+                              (p.flags & RT_RENDER_LANE_WALK) != 0, false, (p.flags & RT_RENDER_MATERIAL_BINS) != 0, (p.flags & (RT_RENDER_COUNT_STEPS | RT_RENDER_COUNT_TESTS)) != 0);
             if (r != RT_OK) return r;
             if (!waited) {   // the job begun before this one adds its sums first (fixed order of the fp32 additions)
                 std::unique_lock<std::mutex> lk(sc->job_mu);

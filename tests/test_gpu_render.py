@@ -274,7 +274,7 @@ def test_full_size_pruned_walk_equals_reference_order_walk(gpu_ctx, integ, axis)
     hs = rt.HostScene.builtin("mesh", bvh_seed=3, bvh_axis=axis)
     gs = gpu_ctx.upload(hs)
     w, h = 1920, 1080
-    a, sa = gs.render_host(w, h, 0, 3, 5, integ, seed=0x5EED)
+    a, sa = gs.render_host(w, h, 0, 3, 5, integ, seed=0x5EED, flags=rt.RENDER_COUNT_STEPS)
     b, sb = gs.render_host(w, h, 0, 3, 5, integ, seed=0x5EED, flags=rt.RENDER_COUNT_TESTS)
     c, _ = gs.render_host(w, h, 0, 3, 5, integ, seed=0x5EED)
     gs.close()
