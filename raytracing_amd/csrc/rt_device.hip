@@ -1030,6 +1030,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : 
 // and stores it as 160 B of state; rays that need the literal NaN-capable box test are listed for a k_trace launch instead.
 #define RT_WALK_STATE_VEC 10u   /* uint4 per ray, stored as [vec][cap] so that every load / store is coalesced */
 #define RT_WS_ODD 1u            /* not a PLAIN ray (zero / non-finite component): left to k_trace's literal mode */
+#ifndef RT_WALK_CHUNK
+#define RT_WALK_CHUNK 512u   /* queue slots a wave claims per atomic */
+#endif
 #ifndef RT_WALK_FETCH_MIN
 #define RT_WALK_FETCH_MIN 8
 #endif
@@ -1139,6 +1142,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     WalkRegs R;
     uint32_t st = WST_IDLE, off = 0u, slot = 0u, aux = 0u;
     bool exhausted = false;        // wave-uniform: the queue has no ray left
+    uint32_t chunk_next = 0u, chunk_end = 0u;   // wave-uniform: the slots this wave has claimed and not yet handed to a lane
     bool any_suspect = false;      // wave-uniform: some lane's ray has a suspect leaf (1 ray in ~1e7)
     uint32_t n_run = 0, n_tri = 0, n_slow = 0, n_iter = 0;   // wave-uniform statistics: lane-steps per block, iterations
 #define F(u) __builtin_bit_cast(float, u)
@@ -1149,14 +1153,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const uint32_t c_idle = (uint32_t)__popcll(m_idle), c_run = (uint32_t)__popcll(m_run), c_tri = (uint32_t)__popcll(m_tri), c_slow = (uint32_t)__popcll(m_slow);
         n_iter += 1u;
         if (!exhausted && c_idle != 0u && (c_idle >= RT_WALK_FETCH_MIN || (c_run | c_tri | c_slow) == 0u)) {
-            // ---- FETCH: the idle lanes take the next rays of the queue (one atomic per wave)
-            uint32_t first = 0u;
-            if (lane == (uint32_t)__builtin_ctzll(m_idle)) first = atomicAdd(next_slot, c_idle);
-            first = (uint32_t)__builtin_amdgcn_readlane((int)first, (int)__builtin_ctzll(m_idle));
-            if (first + c_idle > n) exhausted = true;   // this wave asks no more (others may still hold rays)
+            // ---- FETCH: the idle lanes take the next rays of the wave's chunk; a wave claims RT_WALK_CHUNK queue slots with ONE atomic
+            // (the counter is a single address: an atomic per fetch, 4 M per launch, ran at the rate the memory side serialises them)
+            if (chunk_next >= chunk_end) {
+                uint32_t got = 0u;
+                if (lane == 0u) got = atomicAdd(next_slot, RT_WALK_CHUNK);
+                got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+                if (got >= n) { exhausted = true; any_suspect = __builtin_amdgcn_ballot_w64(st != WST_IDLE && R.s0 != 0xFFFFFFFFu) != 0ull; continue; }   // this wave asks no more
+                chunk_next = got; chunk_end = got + RT_WALK_CHUNK < n ? got + RT_WALK_CHUNK : n;
+            }
+            const uint32_t first = chunk_next, avail = chunk_end - chunk_next;
+            chunk_next += c_idle < avail ? c_idle : avail;
             if (st == WST_IDLE) {
-                const uint32_t mine = first + (uint32_t)__popcll(m_idle & ((1ull << lane) - 1ull));
-                if (mine < n) {
+                const uint32_t rank = (uint32_t)__popcll(m_idle & ((1ull << lane) - 1ull)), mine = first + rank;
+                if (rank < avail) {
                     slot = mine;
                     WalkPack P;
 #pragma unroll
