@@ -304,8 +304,10 @@ def report_kernels(args, R, accum, stats, step_range, rays, spp_step):
     machine) and a 1-spp pass of the counting kernel (reference-order test counts: what the traversal replaces)."""
     rt = R.rt
     b, e = step_range(args.warmup)
-    # (also the step that counts the waves' record steps: the counter is one same-address atomic per wave, 5 % of the frame, so the timed steps run without it)
-    alone = R.render(accum, b, e, flags=rt.RENDER_ONE_LANE | rt.RENDER_COUNT_STEPS, samples_per_pass=stats[0]["samples_per_pass"] if stats else 0)
+    alone = R.render(accum, b, e, flags=rt.RENDER_ONE_LANE, samples_per_pass=stats[0]["samples_per_pass"] if stats else 0)
+    # the waves' record steps come from a step of their own: the counter is one same-address atomic per wave (5 % of the frame), so neither the
+    # timed steps nor the one-lane step above run with it
+    stepped = R.render(accum, b, e, flags=rt.RENDER_COUNT_STEPS, samples_per_pass=stats[0]["samples_per_pass"] if stats else 0)
     counted = R.render(accum, b, b + 1, flags=rt.RENDER_COUNT_TESTS)
     r1 = max(counted["rays"], 1)
     n_box, n_tri, n_sph = counted["box_tests"] / r1, counted["tri_tests"] / r1, counted["sphere_tests"] / r1
@@ -314,7 +316,7 @@ def report_kernels(args, R, accum, stats, step_range, rays, spp_step):
     launches = max(sum(s["trace_launches"] for s in stats), 1)
     shadow_launches = sum(s["trace_shadow_launches"] for s in stats)
     shadow_rays = sum(s["shadow_rays"] for s in stats)
-    wave_steps = alone["trace_wave_steps"] * rays / max(alone["rays"], 1)   # the one-lane step's steps per ray, scaled to the timed rays (same workload, other sample indices)
+    wave_steps = stepped["trace_wave_steps"] * rays / max(stepped["rays"], 1)   # that step's record steps per ray, scaled to the timed rays (same workload and sample indices as the first timed step)
     avg_launch_s = ms_trace / launches / 1e3
     rays_per_launch = rays / launches
     # mean certificate list per direction cell (lists are padded to multiples of four entries), 0 when the scene has no pruned space

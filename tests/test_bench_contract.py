@@ -81,7 +81,8 @@ def test_kernel_trace_summary_beside_it_names_the_roofline_kernel():
     calls, total_ms = sum(int(x["Calls"]) for x in trace), sum(float(x["TotalDurationNs"]) for x in trace) / 1e6
     timed = r["launches"]
     per_step = timed // p["steps"]
-    extra = calls - timed - p["warmup"] * per_step      # the untimed one-lane step
-    assert extra == per_step, (calls, timed, extra)
-    shared_avg = (total_ms - extra * r["one_lane"]["avg_launch_ms"]) / (calls - extra)
+    extra = calls - timed - p["warmup"] * per_step      # the untimed one-lane step, and (from r02h on) the step that counts record steps
+    assert extra in (per_step, 2 * per_step), (calls, timed, extra)
+    # the counting step's launches run like the timed ones (two lanes inside the call), a few percent slower for their counter: priced at the timed average
+    shared_avg = (total_ms - per_step * r["one_lane"]["avg_launch_ms"] - (extra - per_step) * r["avg_launch_ms"]) / (calls - extra)
     assert abs(shared_avg - r["avg_launch_ms"]) < 0.1 * r["avg_launch_ms"], (shared_avg, r["avg_launch_ms"])
