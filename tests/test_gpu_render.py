@@ -276,8 +276,9 @@ def test_full_size_pruned_walk_equals_reference_order_walk(gpu_ctx, integ, axis)
     w, h = 1920, 1080
     a, sa = gs.render_host(w, h, 0, 3, 5, integ, seed=0x5EED, flags=rt.RENDER_COUNT_STEPS)
     b, sb = gs.render_host(w, h, 0, 3, 5, integ, seed=0x5EED, flags=rt.RENDER_COUNT_TESTS)
-    c, _ = gs.render_host(w, h, 0, 3, 5, integ, seed=0x5EED)
+    c, sc_ = gs.render_host(w, h, 0, 3, 5, integ, seed=0x5EED)
     gs.close()
+    assert sc_.as_dict()["trace_wave_steps"] == 0 and sa.as_dict()["trace_wave_steps"] > 0      # the step counter (an atomic per wave) runs only on request
     sa, sb = sa.as_dict(), sb.as_dict()
     assert sa["rays"] == sb["rays"] > 10_000_000
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
