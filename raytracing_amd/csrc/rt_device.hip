@@ -477,18 +477,18 @@ struct RayS { d3 o, d; double time; };  // ray as handed to this traversal level
 // 1e-4 of t_light = light.hit(ray).t, so a lane stops as soon as it ACCEPTS a hit with RN(t - t_light) < -1e-4: up to that
 // accept its walk is the reference's own (same tests, same running best), the reference's final t can only be smaller, and
 // rounding is monotone -- |t_final - t_light| > 1e-4 whatever comes after.  tl() is that ray's t_light.
-template <bool SHADOW_> struct RayFromLdsT {
+template <bool SHADOW_, int STRIDE = 256> struct RayFromLdsT {   // STRIDE: threads per block (the LDS arrays are [component][thread])
     static constexpr bool SHADOW = SHADOW_;
-    lptr<volatile double> slot;  // &lds[threadIdx.x]; component c at slot[c * 256]; 7..9 = 1/d (bounding_box.rs:29), computed once per ray; 10 = t_light (SHADOW)
-    RT_DEV double tl() const { return slot[10 * 256]; }
+    lptr<volatile double> slot;  // &lds[threadIdx.x]; component c at slot[c * STRIDE]; 7..9 = 1/d (bounding_box.rs:29), computed once per ray; 10 = t_light (SHADOW)
+    RT_DEV double tl() const { return slot[10 * STRIDE]; }
     RT_DEV RayS get() const {
         RayS r;
-        r.o = mk(slot[0 * 256], slot[1 * 256], slot[2 * 256]);
-        r.d = mk(slot[3 * 256], slot[4 * 256], slot[5 * 256]);
-        r.time = slot[6 * 256];
+        r.o = mk(slot[0 * STRIDE], slot[1 * STRIDE], slot[2 * STRIDE]);
+        r.d = mk(slot[3 * STRIDE], slot[4 * STRIDE], slot[5 * STRIDE]);
+        r.time = slot[6 * STRIDE];
         return r;
     }
-    RT_DEV d3 inv() const { return mk(slot[7 * 256], slot[8 * 256], slot[9 * 256]); }
+    RT_DEV d3 inv() const { return mk(slot[7 * STRIDE], slot[8 * STRIDE], slot[9 * STRIDE]); }
 };
 typedef RayFromLdsT<false> RayFromLds;
 template <bool SHADOW_> struct RayInRegistersT {
@@ -908,6 +908,10 @@ RT_DEV void traverse(const SceneDev& sc, uint32_t first, const RAYSRC& src, HIT&
     }
 }
 
+#ifndef RT_TRACE_BLOCK
+#define RT_TRACE_BLOCK 64    /* threads per k_trace block: ONE wave.  A block keeps its LDS until its last wave ends, and the walks are long-tailed (mean 260 steps,
+                                * max 5 600): with four waves per block the finished waves' LDS stayed allocated and kept new blocks out.  256 / 128 / 64: 1 960 / 2 018 / 2 090 Mrays/s (r02k) */
+#endif
 #ifndef RT_TRACE_WAVES
 #define RT_TRACE_WAVES 6  /* waves per SIMD the register allocator must leave room for */
 #endif
@@ -919,7 +923,7 @@ RT_DEV void traverse(const SceneDev& sc, uint32_t first, const RAYSRC& src, HIT&
 // (almost) every leaf step runs an exact f64 test and would read the ray back from LDS each time.
 // SHADOW: the rays are MIS visibility rays whose block carries t_light in its last slot; see RayFromLdsT.
 template <bool COUNT, bool INST, bool REGS, bool SHADOW = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : REGS ? RT_TRACE_WAVES_REGS : RT_TRACE_WAVES))) void k_trace(SceneDev sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_fixed,
+__global__ __launch_bounds__(RT_TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(INST ? 2 : REGS ? RT_TRACE_WAVES_REGS : RT_TRACE_WAVES))) void k_trace(SceneDev sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_fixed,
                                                const double* __restrict__ rays, uint32_t cap, double t_min, double t_max,
                                                uint32_t* __restrict__ out_prim, uint32_t* __restrict__ out_inst, double* __restrict__ out_t,
                                                unsigned long long* __restrict__ stats, uint32_t lanes, uint32_t t_stride, PathHit* __restrict__ out_hit,
@@ -934,18 +938,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : 
     const bool valid = (tid & 63u) < lanes && wave_first + (tid & 63u) < n;
     const uint32_t slot = remap ? (valid ? remap[wave_first + (tid & 63u)] : 0u) : wave_first + (tid & 63u);
     const uint32_t path = valid ? (queue ? queue[slot] : slot) : 0u;
-    __shared__ double lds_ray[(SHADOW ? 11 : 10) * 256];
-    __shared__ double lds_best[256];
-    __shared__ uint32_t lds_prim[256], lds_inst[256];
+    __shared__ double lds_ray[(SHADOW ? 11 : 10) * RT_TRACE_BLOCK];
+    __shared__ double lds_best[RT_TRACE_BLOCK];
+    __shared__ uint32_t lds_prim[RT_TRACE_BLOCK], lds_inst[RT_TRACE_BLOCK];
     {
         double* slot = &lds_ray[threadIdx.x];
         const double4* r4 = (const double4*)(rays + (size_t)path * RT_RAY_STRIDE);
         const double4 a = valid ? r4[0] : make_double4(0.0, 0.0, 0.0, 1.0), b = valid ? r4[1] : make_double4(1.0, 1.0, 0.0, 0.0);
-        slot[0 * 256] = a.x; slot[1 * 256] = a.y; slot[2 * 256] = a.z; slot[3 * 256] = a.w; slot[4 * 256] = b.x; slot[5 * 256] = b.y; slot[6 * 256] = b.z;
-        slot[7 * 256] = 1.0 / a.w; slot[8 * 256] = 1.0 / b.x; slot[9 * 256] = 1.0 / b.y;
-        if (SHADOW) slot[10 * 256] = b.w;  // t_light (k_shade)
+        slot[0 * RT_TRACE_BLOCK] = a.x; slot[1 * RT_TRACE_BLOCK] = a.y; slot[2 * RT_TRACE_BLOCK] = a.z; slot[3 * RT_TRACE_BLOCK] = a.w; slot[4 * RT_TRACE_BLOCK] = b.x; slot[5 * RT_TRACE_BLOCK] = b.y; slot[6 * RT_TRACE_BLOCK] = b.z;
+        slot[7 * RT_TRACE_BLOCK] = 1.0 / a.w; slot[8 * RT_TRACE_BLOCK] = 1.0 / b.x; slot[9 * RT_TRACE_BLOCK] = 1.0 / b.y;
+        if (SHADOW) slot[10 * RT_TRACE_BLOCK] = b.w;  // t_light (k_shade)
     }
-    RayFromLdsT<SHADOW> src; src.slot = (lptr<volatile double>)&lds_ray[threadIdx.x];  // each lane reads back only its own slot: no barrier needed
+    RayFromLdsT<SHADOW, RT_TRACE_BLOCK> src; src.slot = (lptr<volatile double>)&lds_ray[threadIdx.x];  // each lane reads back only its own slot: no barrier needed
     RayInRegistersT<SHADOW> src_regs;
     if (REGS) { src_regs.r = src.get(); src_regs.rinv = src.inv(); src_regs.t_light = SHADOW ? src.tl() : 0.0; }
     LaneHit h;
@@ -960,7 +964,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INST ? 2 : 
         traverse<0, COUNT, INST, RayInRegistersT<SHADOW>, LaneHitRegs>(sc, sc.root_off, src_regs, hr, valid, t_min, RT_NONE, cnt);
         h.best = (double)hr.best; h.prim = (uint32_t)hr.prim; h.inst = (uint32_t)hr.inst;
     } else {
-        traverse<0, COUNT, INST, RayFromLdsT<SHADOW>, LaneHit>(sc, sc.root_off, src, h, valid, t_min, RT_NONE, cnt);
+        traverse<0, COUNT, INST, RayFromLdsT<SHADOW, RT_TRACE_BLOCK>, LaneHit>(sc, sc.root_off, src, h, valid, t_min, RT_NONE, cnt);
     }
 #ifdef RT_TRACE_DIAG
     cnt.cyc_total = __builtin_readcyclecounter() - cnt.cyc_total;
@@ -2017,8 +2021,9 @@ static void launch_trace(rt_scene* sc, unsigned long long* lstats, uint32_t lcap
     if (n_bound == 0) return;
     SceneDev dv = sc->dev;   // this launch's copy of the kernel argument
     dv.count_steps = count_steps ? 1u : 0u;
-    const dim3 grid((uint32_t)((((uint64_t)n_bound + lanes - 1u) / lanes + 3u) / 4u));  // waves of `lanes` rays, four waves per block
-#define RT_LAUNCH_TRACE_S(C, I, R, S) hipLaunchKernelGGL((k_trace<C, I, R, S>), grid, dim3(256), 0, st, dv, queue, n_ptr, n_bound, rays, lcap, t_min, t_max, out_prim, out_inst, out_t, lstats, lanes, t_stride, out_hit, remap)
+    const uint32_t wpb = RT_TRACE_BLOCK / 64u;
+    const dim3 grid((uint32_t)((((uint64_t)n_bound + lanes - 1u) / lanes + wpb - 1u) / wpb));  // waves of `lanes` rays, RT_TRACE_BLOCK / 64 waves per block
+#define RT_LAUNCH_TRACE_S(C, I, R, S) hipLaunchKernelGGL((k_trace<C, I, R, S>), grid, dim3(RT_TRACE_BLOCK), 0, st, dv, queue, n_ptr, n_bound, rays, lcap, t_min, t_max, out_prim, out_inst, out_t, lstats, lanes, t_stride, out_hit, remap)
 #define RT_LAUNCH_TRACE_R(C, I, R) do { if (shadow && !C) RT_LAUNCH_TRACE_S(C, I, R, !C); else RT_LAUNCH_TRACE_S(C, I, R, false); } while (0)
 #define RT_LAUNCH_TRACE(C, I) do { if (sc->reg_ray) RT_LAUNCH_TRACE_R(C, I, true); else RT_LAUNCH_TRACE_R(C, I, false); } while (0)
     const bool inst = sc->has_instances;  // scenes without BVHNode objects use the kernel variant compiled without the nested walk
