@@ -1473,6 +1473,10 @@ RT_DEV void push_queue_keyed(bool want, uint32_t path, uint32_t key, uint32_t* _
 // k_shade extends its two queues with ONE atomic per block and queue (after RT_SHADE_TILES tiles of 256 slots), not one per wave: the
 // counters are single addresses, and device-scope atomics on one address from 8 XCDs serialise at several ns each -- 6 M of them per
 // 50-spp pass were a third of k_shade's time (r02g: one per 256 slots 1 837 -> 1 965 Mrays/s, same frame).
+#ifndef RT_SHADE_BLOCK
+#define RT_SHADE_BLOCK 256u   /* threads per k_shade block */
+#endif
+#define RT_SHADE_WPB (RT_SHADE_BLOCK / 64u)
 #ifndef RT_SHADE_TILES
 #define RT_SHADE_TILES 1u   /* measured: 1 tile 1 955, 4 tiles 1 908, 8 tiles 1 909 Mrays/s (per-wave atomics: 1 838) */
 #endif
@@ -1566,7 +1570,7 @@ __global__ __launch_bounds__(256) void k_bin_scatter(const uint8_t* __restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void k_shade(SceneDev sc, PathBuffers pb, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ order, const uint32_t* __restrict__ n_ptr,
+__global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(SceneDev sc, PathBuffers pb, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ order, const uint32_t* __restrict__ n_ptr,
                                                uint32_t bounce, int32_t max_depth, int32_t integrator, uint64_t seed,
                                                uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_keys, uint32_t* __restrict__ next_count,
                                                uint32_t* __restrict__ shadow_queue, uint32_t* __restrict__ shadow_keys, uint32_t* __restrict__ shadow_count) {
@@ -1574,14 +1578,14 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, PathBuffers pb, cons
     // A block shades RT_SHADE_TILES tiles of 256 queue slots one after the other and parks what each thread wants to push in LDS; the
     // queues are then extended with ONE atomic per block and queue (push_tiles_block).  Whole blocks leave together: every wave of a
     // live block takes part in the barriers.
-    const uint32_t block_first = blockIdx.x * (256u * RT_SHADE_TILES);
+    const uint32_t block_first = blockIdx.x * (RT_SHADE_BLOCK * RT_SHADE_TILES);
     if (block_first >= n) return;
-    __shared__ uint32_t st_path[RT_SHADE_TILES][256], st_nkey[RT_SHADE_TILES][256], st_skey[RT_SHADE_TILES][256];
-    __shared__ uint8_t st_flag[RT_SHADE_TILES][256];
+    __shared__ uint32_t st_path[RT_SHADE_TILES][RT_SHADE_BLOCK], st_nkey[RT_SHADE_TILES][RT_SHADE_BLOCK], st_skey[RT_SHADE_TILES][RT_SHADE_BLOCK];
+    __shared__ uint8_t st_flag[RT_SHADE_TILES][RT_SHADE_BLOCK];
     const uint32_t cap = pb.cap;
 #pragma unroll 1
     for (uint32_t tile = 0; tile < RT_SHADE_TILES; ++tile) {
-    const uint32_t gid = block_first + tile * 256u + threadIdx.x;
+    const uint32_t gid = block_first + tile * RT_SHADE_BLOCK + threadIdx.x;
     const bool valid = gid < n;
     bool want_next = false, want_shadow = false;
     uint32_t path = 0, next_key = 0, shadow_key = 0;
@@ -1729,18 +1733,18 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, PathBuffers pb, cons
     st_flag[tile][threadIdx.x] = (uint8_t)((want_next ? 1u : 0u) | (want_shadow ? 2u : 0u));
     }
     // every thread reads back only what it parked itself: no barrier needed before this point
-    __shared__ uint32_t cnt_s[2][RT_SHADE_TILES * 4u], base_s[2];
+    __shared__ uint32_t cnt_s[2][RT_SHADE_TILES * RT_SHADE_WPB], base_s[2];
     const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
 #pragma unroll
     for (uint32_t tile = 0; tile < RT_SHADE_TILES; ++tile) {
         const uint32_t fl = st_flag[tile][threadIdx.x];
         const uint64_t ma = __ballot((fl & 1u) != 0u), mb = __ballot((fl & 2u) != 0u);
-        if (lane == 0u) { cnt_s[0][tile * 4u + wv] = (uint32_t)__popcll(ma); cnt_s[1][tile * 4u + wv] = (uint32_t)__popcll(mb); }
+        if (lane == 0u) { cnt_s[0][tile * RT_SHADE_WPB + wv] = (uint32_t)__popcll(ma); cnt_s[1][tile * RT_SHADE_WPB + wv] = (uint32_t)__popcll(mb); }
     }
     __syncthreads();
     if (threadIdx.x < 2u) {
         uint32_t tot = 0u;
-        for (uint32_t k = 0; k < RT_SHADE_TILES * 4u; ++k) tot += cnt_s[threadIdx.x][k];
+        for (uint32_t k = 0; k < RT_SHADE_TILES * RT_SHADE_WPB; ++k) tot += cnt_s[threadIdx.x][k];
         base_s[threadIdx.x] = tot ? atomicAdd(threadIdx.x == 0u ? next_count : shadow_count, tot) : 0u;
     }
     __syncthreads();
@@ -1749,9 +1753,9 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, PathBuffers pb, cons
     for (uint32_t tile = 0; tile < RT_SHADE_TILES; ++tile) {   // slots inside a block: tile, then wave, then lane
         uint32_t ba = 0u, bb = 0u;
 #pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) {
+        for (uint32_t k = 0; k < RT_SHADE_WPB; ++k) {
             if (k == wv) { ba = ra; bb = rb; }
-            ra += cnt_s[0][tile * 4u + k]; rb += cnt_s[1][tile * 4u + k];
+            ra += cnt_s[0][tile * RT_SHADE_WPB + k]; rb += cnt_s[1][tile * RT_SHADE_WPB + k];
         }
         const uint32_t fl = st_flag[tile][threadIdx.x], path = st_path[tile][threadIdx.x];
         const uint64_t ma = __ballot((fl & 1u) != 0u), mb = __ballot((fl & 2u) != 0u);
@@ -2162,10 +2166,10 @@ static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bo
         }
         // shade appends survivors (and, when sorting, their coherence keys) compactly to the raw queues
         if (sort_rays)
-            hipLaunchKernelGGL(k_shade, dim3((live + 256u * RT_SHADE_TILES - 1u) / (256u * RT_SHADE_TILES)), dim3(256), 0, st, sc->dev, pbk, ws.queue[cur], order, ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
+            hipLaunchKernelGGL(k_shade, dim3((live + RT_SHADE_BLOCK * RT_SHADE_TILES - 1u) / (RT_SHADE_BLOCK * RT_SHADE_TILES)), dim3(RT_SHADE_BLOCK), 0, st, sc->dev, pbk, ws.queue[cur], order, ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
                                seed, ws.raw_queue, ws.raw_keys, ws.counts + nxt, ws.raw_squeue, ws.raw_skeys, ws.counts + 2);
         else
-            hipLaunchKernelGGL(k_shade, dim3((live + 256u * RT_SHADE_TILES - 1u) / (256u * RT_SHADE_TILES)), dim3(256), 0, st, sc->dev, pbk, ws.queue[cur], order, ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
+            hipLaunchKernelGGL(k_shade, dim3((live + RT_SHADE_BLOCK * RT_SHADE_TILES - 1u) / (RT_SHADE_BLOCK * RT_SHADE_TILES)), dim3(RT_SHADE_BLOCK), 0, st, sc->dev, pbk, ws.queue[cur], order, ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
                                seed, ws.queue[nxt], (uint32_t*)nullptr, ws.counts + nxt, ws.shadow_queue, (uint32_t*)nullptr, ws.counts + 2);
         HIP_OK(hipMemcpyAsync(ws.h_counts, ws.counts, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
