@@ -265,6 +265,31 @@ def test_edge_cases(gpu_ctx):
     gs.close()
 
 
+# BASELINE.json configs[0..4] exactly as bench.py's WORKLOADS runs them (scene, frame, integrator, depth, the bench's default tree)
+BASELINE_CONFIGS = [("random", 400, 225, rt.INT_MIS, 50, 4), ("mesh", 1920, 1080, rt.INT_BRDF, 5, 1), ("mesh", 1920, 1080, rt.INT_MIS, 5, 1),
+                    ("simple", 1920, 1080, rt.INT_BRDF, 5, 1), ("simple_triangle", 3840, 2160, rt.INT_MIS, 5, 1)]
+
+
+@pytest.mark.parametrize("name,w,h,integ,depth,spp", BASELINE_CONFIGS, ids=["configs0", "configs1", "configs2", "configs3", "configs4"])
+def test_baseline_configs_at_their_full_frame_size(gpu_ctx, name, w, h, integ, depth, spp):
+    # every BASELINE.json config at ITS OWN width x height and depth, on the tree the bench renders (min-area axes, seed 3):
+    #  (1) 300 samples drawn over the whole frame and the first 1000 spp against the oracle's recursive integrator (1e-9 / signatures, as above);
+    #  (2) whole frames: the production kernel and the reference-order counting kernel give bit-identical accumulators, no shortcut contradicted.
+    hs = rt.HostScene.builtin(name, bvh_seed=3, bvh_axis="min_area")
+    osc = orc.OracleScene(hs.describe())
+    gs = gpu_ctx.upload(hs)
+    rng = np.random.default_rng(w + depth)
+    picks = [(int(rng.integers(w)), int(rng.integers(h)), int(rng.integers(0, 1000))) for _ in range(300)]
+    _sample_compare(gs, osc, w, h, picks, depth, integ, seed=0xBA5E)
+    a, sa = gs.render_host(w, h, 0, spp, depth, integ, seed=0xBA5E)
+    b, sb = gs.render_host(w, h, 0, spp, depth, integ, seed=0xBA5E, flags=rt.RENDER_COUNT_TESTS)
+    gs.close()
+    sa, sb = sa.as_dict(), sb.as_dict()
+    assert sa["paths"] == sb["paths"] == w * h * spp and sa["rays"] == sb["rays"] > sa["paths"]
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert sb["filter_violations"] == 0 and sb["box_tests"] + sb["tri_tests"] + sb["sphere_tests"] >= sb["rays"]   # the earth scene has no BVH: one sphere test per ray
+
+
 @pytest.mark.parametrize("integ,axis", [(rt.INT_BRDF, "seeded"), (rt.INT_MIS, "seeded"), (rt.INT_MIS, "min_area")])
 def test_full_size_pruned_walk_equals_reference_order_walk(gpu_ctx, integ, axis):
     # BASELINE.json's full frame (pagoda, 1920x1080, depth 5): the production kernel (fp32 filters, strict pruning, ~1 % of
