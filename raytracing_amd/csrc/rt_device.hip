@@ -1477,6 +1477,11 @@ RT_DEV void push_queue_keyed(bool want, uint32_t path, uint32_t key, uint32_t* _
 #define RT_SHADE_BLOCK 256u   /* threads per k_shade block */
 #endif
 #define RT_SHADE_WPB (RT_SHADE_BLOCK / 64u)
+#ifdef RT_SHADE_WAVES   /* waves per SIMD the register allocator must make room for (default: whatever 148 VGPRs allow = 3) */
+#define RT_SHADE_OCCUPANCY __attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES, RT_SHADE_WAVES)))
+#else
+#define RT_SHADE_OCCUPANCY
+#endif
 #ifndef RT_SHADE_TILES
 #define RT_SHADE_TILES 1u   /* measured: 1 tile 1 955, 4 tiles 1 908, 8 tiles 1 909 Mrays/s (per-wave atomics: 1 838) */
 #endif
@@ -1570,7 +1575,7 @@ __global__ __launch_bounds__(256) void k_bin_scatter(const uint8_t* __restrict__
     }
 }
 
-__global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(SceneDev sc, PathBuffers pb, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ order, const uint32_t* __restrict__ n_ptr,
+__global__ __launch_bounds__(RT_SHADE_BLOCK) RT_SHADE_OCCUPANCY void k_shade(SceneDev sc, PathBuffers pb, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ order, const uint32_t* __restrict__ n_ptr,
                                                uint32_t bounce, int32_t max_depth, int32_t integrator, uint64_t seed,
                                                uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_keys, uint32_t* __restrict__ next_count,
                                                uint32_t* __restrict__ shadow_queue, uint32_t* __restrict__ shadow_keys, uint32_t* __restrict__ shadow_count) {
