@@ -13,14 +13,6 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def _gpu_available():
-    try:
-        import raytracing_amd._ffi as ffi
-        return ffi.hip().rt_device_count() > 0
-    except Exception:
-        return False
-
-
 @pytest.fixture(scope="session")
 def gpu_ctx():
     import raytracing_amd as rt
