@@ -510,8 +510,16 @@ RT_DEV bool ray_is_plain(d3 o, d3 inv) {  // box_axis_fast precondition: no NaN 
 }
 
 // transform.rs:25-32: the ray in the space of transform `xform` (RT_NONE: the ray itself)
+// PLAIN (every ray of the wave has finite coordinates and finite non-zero direction components) and xform == sc.translate_xf (the
+// pagoda wraps every triangle in from_translation(5,5,5), main.rs:815-818): the matrix product ((1 x + 0 y) + 0 z) + t w rounds to
+// x + t for the origin (the zeros add exactly, t != 0 absorbs the sign of a zero sum) and to x itself for the direction (x != 0,
+// w = 0), so the shortcut below is the reference's result bit for bit at 3 additions instead of 21 multiplications and 18 additions.
+template <bool PLAIN = false>
 RT_DEV void apply_xform(const SceneDev& sc, uint32_t xform, const RayS& ray, d3& xo, d3& xd) {
-    if (xform != RT_NONE) {
+    if (PLAIN && xform != RT_NONE && xform == sc.translate_xf) {
+        cptr<double> m = as_const(sc.xforms[xform].t_inv);
+        xo = mk(ray.o.x + m[12], ray.o.y + m[13], ray.o.z + m[14]); xd = ray.d;
+    } else if (xform != RT_NONE) {
         cptr<double> m = as_const(sc.xforms[xform].t_inv);
         double mm[16];
 #pragma unroll
@@ -654,7 +662,7 @@ RT_DEV bool tri2_exact(const SceneDev& sc, uint32_t node, uint32_t rec_off, lane
 #endif
     const RayS ray = src.get();
     d3 xo, xd;
-    apply_xform(sc, cur_xf, ray, xo, xd);
+    apply_xform<MODE == BOX_PLAIN>(sc, cur_xf, ray, xo, xd);
     const bool pass = mask_lane(m_pass);
     bool changed = false;
 #pragma unroll
@@ -719,7 +727,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
     if (prune) {
         const RayS ray = src.get();
         d3 xo, xd;
-        apply_xform(sc, sc.prune_xf, ray, xo, xd);
+        apply_xform<MODE == BOX_PLAIN>(sc, sc.prune_xf, ray, xo, xd);
         Suspects sus;
         const bool c = ray_certified(sc, node_off, xo, xd, sus) && active && ray.time >= sc.prune_time0 && ray.time <= sc.prune_time1;
         if (COUNT) cnt.uncertified += (active && !c) ? 1u : 0u;
@@ -746,7 +754,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
         {
             const RayS ray = src.get();
             d3 xo, xd;
-            apply_xform(sc, cur_xf, ray, xo, xd);
+            apply_xform<MODE == BOX_PLAIN>(sc, cur_xf, ray, xo, xd);
             tri_filter_init(tf, xo, xd);
             if (prune && cur_xf == sc.prune_xf) {  // inner records carry boxes of THIS space only
                 const bool ok = strict_filter_init(ps.sf, xo, xd, sc);
@@ -816,7 +824,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
                 const uint32_t nsph = wword<9>(w);
                 const RayS ray = src.get();
                 d3 xo, xd;
-                apply_xform(sc, wword<8>(w), ray, xo, xd);
+                apply_xform<MODE == BOX_PLAIN>(sc, wword<8>(w), ray, xo, xd);
                 const bool pass = mask_lane(m_pass);
                 if (COUNT) cnt.sph += pass ? (nsph + ((rec & RT_NODE_DUP_RIGHT) ? 1u : 0u)) : 0u;
                 double t;
@@ -862,7 +870,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
                 const GeomS g0 = load_geom(geom, p0);
                 const RayS ray = src.get();
                 d3 xo, xd;
-                apply_xform(sc, x0, ray, xo, xd);
+                apply_xform<MODE == BOX_PLAIN>(sc, x0, ray, xo, xd);
                 bool changed = test_prim<LEVEL, COUNT, INST, HIT>(sc, p0, g0, pass, ray, h, xo, xd, t_min, inst_prim, cnt);
                 if (p1 != RT_NONE) {
                     const GeomS g1 = load_geom(geom, p1);
@@ -870,7 +878,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
                         changed |= test_prim<LEVEL, COUNT, INST, HIT>(sc, p1, g1, pass, ray, h, xo, xd, t_min, inst_prim, cnt);
                     } else {  // second primitive of a leaf under a different matrix: one-off transform
                         d3 yo, yd;
-                        apply_xform(sc, g1.xform, ray, yo, yd);
+                        apply_xform<MODE == BOX_PLAIN>(sc, g1.xform, ray, yo, yd);
                         changed |= test_prim<LEVEL, COUNT, INST, HIT>(sc, p1, g1, pass, ray, h, yo, yd, t_min, inst_prim, cnt);
                     }
                 }
@@ -2936,6 +2944,22 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     v.cert_cells = sc->d_cert_cells; v.cert_entries = sc->d_cert_entries; v.cert_normals = sc->d_cert_normals;
     v.cert_planes = sc->d_cert_planes; v.cert_plane_off = sc->d_cert_plane_off; v.cert_plane_leaf = sc->d_cert_plane_leaf; v.cert_n_normals = (uint32_t)(pr.normals.size() / 3); v.prune_time0 = pr.time0; v.prune_time1 = pr.time1; v.prune_delta_coef = pr.delta_coef;
     v.prune_on = pr.on ? 1u : 0u; v.prune_xf = pr.xf;
+    v.translate_xf = RT_NONE;
+    {   // apply_xform<true>'s shortcut: the pruned space's transform if it qualifies, else the first that does
+        const rt_xform* xf = (const rt_xform*)((const uint8_t*)blob + h.off_xforms);
+        auto pure_translation = [&](uint32_t i) {
+            const double* m = xf[i].t_inv;
+            for (int c = 0; c < 3; ++c)
+                for (int r = 0; r < 3; ++r) if (m[4 * c + r] != (r == c ? 1.0 : 0.0)) return false;
+            for (int r = 0; r < 3; ++r) if (!std::isfinite(m[12 + r]) || m[12 + r] == 0.0) return false;
+            return true;
+        };
+        if (pr.on && pr.xf != RT_NONE && pr.xf < h.n_xforms && pure_translation(pr.xf)) v.translate_xf = pr.xf;
+        else for (uint32_t i = 0; i < h.n_xforms && v.translate_xf == RT_NONE; ++i) if (pure_translation(i)) v.translate_xf = i;
+    }
+#ifdef RT_NO_TRANSLATE_SHORTCUT   /* A/B */
+    v.translate_xf = RT_NONE;
+#endif
     v.prune_tau_coef = pr.tau_coef; v.prune_radius = pr.radius; v.prune_box_abs_max = pr.box_abs_max;
     v.n_nodes = h.n_nodes; v.boxes_finite = boxes_finite ? 1u : 0u;
     v.camera = h.camera; v.n_lights = h.n_lights; v.root_node = h.root_node; v.root_end = h.root_end; v.background = h.background;

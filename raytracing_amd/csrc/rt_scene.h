@@ -47,6 +47,8 @@ struct SceneDev {
     rt_camera camera;
     uint32_t n_lights, root_node, root_end, background;
     uint32_t n_nodes, boxes_finite;
+    uint32_t translate_xf;  // a transform whose inverse is exactly identity + a translation with three finite non-zero components (RT_NONE: none):
+                            // for rays without zero / non-finite components apply_xform<true> adds the translation instead of multiplying the matrix out
     uint32_t count_steps;   // per launch (launch_trace's copy): k_trace adds its waves' record steps to stats[15] -- one same-address atomic per wave, 5 % of the frame, so only on request
     float sort_min[3], sort_scale[3];  // origin quantisation grid of the ray-sorting key
 };
