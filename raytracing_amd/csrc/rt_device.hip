@@ -1583,10 +1583,15 @@ __global__ __launch_bounds__(256) void k_bin_scatter(const uint8_t* __restrict__
     }
 }
 
-__global__ __launch_bounds__(RT_SHADE_BLOCK) RT_SHADE_OCCUPANCY void k_shade(SceneDev sc, PathBuffers pb, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ order, const uint32_t* __restrict__ n_ptr,
-                                               uint32_t bounce, int32_t max_depth, int32_t integrator, uint64_t seed,
-                                               uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_keys, uint32_t* __restrict__ next_count,
-                                               uint32_t* __restrict__ shadow_queue, uint32_t* __restrict__ shadow_keys, uint32_t* __restrict__ shadow_count) {
+#define RT_SHADE_PARAMS SceneDev sc, PathBuffers pb, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ order, const uint32_t* __restrict__ n_ptr, \
+                        uint32_t bounce, int32_t max_depth, int32_t integrator, uint64_t seed,                                                                    \
+                        uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_keys, uint32_t* __restrict__ next_count,                                    \
+                        uint32_t* __restrict__ shadow_queue, uint32_t* __restrict__ shadow_keys, uint32_t* __restrict__ shadow_count
+#define RT_SHADE_ARGS sc, pb, queue, order, n_ptr, bounce, max_depth, integrator, seed, next_queue, next_keys, next_count, shadow_queue, shadow_keys, shadow_count
+RT_DEV void shade_block(const SceneDev& sc, const PathBuffers& pb, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ order, const uint32_t* __restrict__ n_ptr,
+                        uint32_t bounce, int32_t max_depth, int32_t integrator, uint64_t seed,
+                        uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_keys, uint32_t* __restrict__ next_count,
+                        uint32_t* __restrict__ shadow_queue, uint32_t* __restrict__ shadow_keys, uint32_t* __restrict__ shadow_count) {
     const uint32_t n = *n_ptr;
     // A block shades RT_SHADE_TILES tiles of 256 queue slots one after the other and parks what each thread wants to push in LDS; the
     // queues are then extended with ONE atomic per block and queue (push_tiles_block).  Whole blocks leave together: every wave of a
@@ -1776,6 +1781,12 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) RT_SHADE_OCCUPANCY void k_shade(Sce
         if (fl & 2u) { const uint32_t sl = bb + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull)); shadow_queue[sl] = path; if (shadow_keys) shadow_keys[sl] = st_skey[tile][threadIdx.x]; }
     }
 }
+// Two builds of the same body.  k_shade: the allocator's own choice (148 VGPRs, 3 waves per SIMD) -- for the scenes whose frame is bound by k_trace's
+// issue slots, where a faster k_shade only hands its time to the k_trace of the other lane.  k_shade_dense: 4 waves per SIMD (128 VGPRs + 88 B of
+// scratch), a third faster on its own -- for the small scenes (no ray sorting: earth, broken cube), where shading is the larger half of the frame:
+// +4 % there, -2 % on the pagoda.
+__global__ __launch_bounds__(RT_SHADE_BLOCK) RT_SHADE_OCCUPANCY void k_shade(RT_SHADE_PARAMS) { shade_block(RT_SHADE_ARGS); }
+__global__ __launch_bounds__(RT_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_shade_dense(RT_SHADE_PARAMS) { shade_block(RT_SHADE_ARGS); }
 
 // ------------------------------------------------------------------------------------------------
 // k_unwind / k_accumulate / k_resolve
@@ -2182,7 +2193,7 @@ static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bo
             hipLaunchKernelGGL(k_shade, dim3((live + RT_SHADE_BLOCK * RT_SHADE_TILES - 1u) / (RT_SHADE_BLOCK * RT_SHADE_TILES)), dim3(RT_SHADE_BLOCK), 0, st, sc->dev, pbk, ws.queue[cur], order, ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
                                seed, ws.raw_queue, ws.raw_keys, ws.counts + nxt, ws.raw_squeue, ws.raw_skeys, ws.counts + 2);
         else
-            hipLaunchKernelGGL(k_shade, dim3((live + RT_SHADE_BLOCK * RT_SHADE_TILES - 1u) / (RT_SHADE_BLOCK * RT_SHADE_TILES)), dim3(RT_SHADE_BLOCK), 0, st, sc->dev, pbk, ws.queue[cur], order, ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
+            hipLaunchKernelGGL(k_shade_dense, dim3((live + RT_SHADE_BLOCK * RT_SHADE_TILES - 1u) / (RT_SHADE_BLOCK * RT_SHADE_TILES)), dim3(RT_SHADE_BLOCK), 0, st, sc->dev, pbk, ws.queue[cur], order, ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
                                seed, ws.queue[nxt], (uint32_t*)nullptr, ws.counts + nxt, ws.shadow_queue, (uint32_t*)nullptr, ws.counts + 2);
         HIP_OK(hipMemcpyAsync(ws.h_counts, ws.counts, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
