@@ -26,13 +26,13 @@ struct SceneDev {
     const uint8_t* texels;
     const rt_light* lights;
     const uint8_t* mat_uses_uv;
-    const uint8_t* stream;  // trace stream (rt_device.hip): fp32 filter records in pre-order; production form (always-entered inner nodes have no record)
+    const uint8_t* stream;  // trace stream (rt_trace.hip.h): fp32 filter records in pre-order; production form (always-entered inner nodes have no record)
     const uint32_t* node_off;  // [n_nodes + 1] byte offset of each node's record in `stream` (a node without record: its first child's)
     const uint8_t* stream_full;     // the same with a record for every node: counting kernel, NaN-capable waves
     const uint32_t* node_off_full;
     uint32_t root_off_full;
     double box_abs_max;        // max |coordinate| over the finite boxes (box filter error bound)
-    // strict pruning (rt_device.hip, StrictFilter / ray_certified): one transform space, its direction grid and error constants
+    // strict pruning (rt_trace.hip.h, StrictFilter / ray_certified): one transform space, its direction grid and error constants
     const uint32_t* cert_cells;    // [3 K K + 1] CSR offsets into cert_entries
     const void* cert_entries;      // CertEntry[]: fp32 normal + index into cert_normals, lists padded to multiples of 4
     const double* cert_normals;    // 3 per distinct unit normal of the pruned space
