@@ -400,6 +400,7 @@ struct PruneState {
     lanemask enable;
     uint32_t s0, s1, s2;
     bool any_suspect;  // wave-uniform
+    uint32_t none;     // wave-uniform: 1 iff enable == 0 (kept as an integer: the hot loop tests it together with the record kind)
 };
 RT_DEV lanemask mask_lt_u32(uint32_t v, uint32_t s) { lanemask m; asm("v_cmp_lt_u32_e64 %0, %1, %2" : "=s"(m) : "v"(v), "s"(s)); return m; }
 
@@ -533,19 +534,24 @@ RT_DEV bool box_exact(cptr<rt_node> nodes, uint32_t rec, d3 o, d3 inv, double t_
 }
 
 // One record's box test for the wave: returns the mask of lanes that descend and moves the others to skip(record).
-// `strict` (wave-uniform): the record is an inner one, whose local box may prune (StrictFilter).
+// `not_strict` (wave-uniform): 0 iff the record is an inner one, whose local box may prune (StrictFilter).
 template <int B, int MODE, bool COUNT, class RAYSRC, class HIT>
-RT_DEV lanemask box_step(const Window& w, const BoxFilter& bf, const PruneState& ps, bool strict, uint32_t off, uint32_t& wait, uint32_t rec,
+RT_DEV lanemask box_step(const Window& w, const BoxFilter& bf, const PruneState& ps, uint32_t not_strict, uint32_t off, uint32_t& wait, uint32_t rec,
                          cptr<rt_node> nodes, const RAYSRC& src, HIT& h, double t_min, LaneCount& cnt) {
     const lanemask m_act = mask_reached(off, wait);
 #ifdef RT_TRACE_DIAG
     cnt.lane_steps += mask_lane(m_act) ? 1u : 0u;
 #endif
     if (COUNT) cnt.box += (mask_lane(m_act) && !(rec & RT_NODE_NO_BOX)) ? 1u : 0u;
-    lanemask m_pass;
+    lanemask m_pass = 0ull;
     if (MODE == BOX_PLAIN) {
         lanemask cp = 0ull, cf = 0ull, sp = 0ull;
-        if (strict && ps.enable != 0ull && wword<B + 8>(w) != 0xFF800000u) {  // a local box starting at -inf is the (-inf, +inf) box of a subtree that is never pruned
+        // (a subtree that is never pruned carries the local box (-inf, +inf): near = -inf, far = +inf for every enabled lane -- their fp32 1/d is finite
+        // and non-zero -- so the filter itself answers "not pruned"; testing for it here would cost every step two scalar instructions)
+        uint32_t no_strict_test = not_strict | ps.none;
+        no_strict_test = (uint32_t)__builtin_amdgcn_readfirstlane((int)no_strict_test);
+        asm("" : "+s"(no_strict_test));
+        if (no_strict_test == 0u) {
             sp = strict_filter<B + 8>(ps.sf, w) & ps.enable;
             if (ps.any_suspect) {  // a subtree that holds one of the ray's suspect leaves is not pruned
                 const uint32_t span = wword<B + 6>(w) - off;
@@ -553,29 +559,27 @@ RT_DEV lanemask box_step(const Window& w, const BoxFilter& bf, const PruneState&
             }
         }
         const lanemask sp_apply = COUNT ? 0ull : sp;  // the counting kernel walks the reference's own visited set
-#if RT_STRICT_FIRST
-        if (!COUNT && (m_act & ~sp_apply) == 0ull) {  // every ray that is here is pruned: the reference's own test decides nothing
-            wait = mask_select(wait, wword<B + 6>(w), m_act);
-            return 0ull;
-        }
-#endif
-        box_filter<B>(bf, w, cp, cf);
-        m_pass = m_act & cp & ~sp_apply;
-        if (COUNT || (m_act & ~(cp | cf | sp_apply)) != 0ull) {  // rare: a plane value within the error bound of best / t_min
+        // RT_STRICT_FIRST: when every ray that is here is pruned the reference's own test decides nothing -- m_pass stays 0 (ONE exit: an
+        // early return leaves the compiler a "returned early" flag to carry as a lane mask through the rest of the step)
+        if (COUNT || !RT_STRICT_FIRST || (m_act & ~sp_apply) != 0ull) {
+            box_filter<B>(bf, w, cp, cf);
+            m_pass = m_act & cp & ~sp_apply;
+            if (COUNT || (m_act & ~(cp | cf | sp_apply)) != 0ull) {  // rare: a plane value within the error bound of best / t_min
 #ifdef RT_TRACE_DIAG
-            const uint64_t cx0 = __builtin_readcyclecounter();
+                const uint64_t cx0 = __builtin_readcyclecounter();
 #endif
-            const RayS ray = src.get();
-            const bool act = mask_lane(m_act);
-            const bool ex = act & box_exact<true>(nodes, rec, ray.o, src.inv(), t_min, h.best);
-            if (COUNT) {
-                cnt.bad += (act & ((mask_lane(cp) & !ex) | (mask_lane(cf) & ex))) ? 1u : 0u;
-                if (ex && mask_lane(sp) && off >= cnt.pruned_until) cnt.pruned_until = wword<B + 6>(w);  // pruning would skip up to here
+                const RayS ray = src.get();
+                const bool act = mask_lane(m_act);
+                const bool ex = act & box_exact<true>(nodes, rec, ray.o, src.inv(), t_min, h.best);
+                if (COUNT) {
+                    cnt.bad += (act & ((mask_lane(cp) & !ex) | (mask_lane(cf) & ex))) ? 1u : 0u;
+                    if (ex && mask_lane(sp) && off >= cnt.pruned_until) cnt.pruned_until = wword<B + 6>(w);  // pruning would skip up to here
+                }
+                m_pass = __builtin_amdgcn_ballot_w64(ex) & ~sp_apply;
+#ifdef RT_TRACE_DIAG
+                cnt.exact_box += 1; cnt.cyc_xbox += __builtin_readcyclecounter() - cx0;
+#endif
             }
-            m_pass = __builtin_amdgcn_ballot_w64(ex) & ~sp_apply;
-#ifdef RT_TRACE_DIAG
-            cnt.exact_box += 1; cnt.cyc_xbox += __builtin_readcyclecounter() - cx0;
-#endif
         }
     } else {
         const RayS ray = src.get();
@@ -658,7 +662,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
     uint32_t off = first, cur_xf = prune ? sc.prune_xf : RT_NONE;
     lanemask clean = 0ull;
     PruneState ps;
-    ps.enable = 0ull; ps.s0 = ps.s1 = ps.s2 = 0xFFFFFFFFu; ps.any_suspect = false;
+    ps.enable = 0ull; ps.none = 1u; ps.s0 = ps.s1 = ps.s2 = 0xFFFFFFFFu; ps.any_suspect = false;
     if (prune) {
         const RayS ray = src.get();
         d3 xo, xd;
@@ -685,7 +689,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
     }
     for (;;) {  // one round per transform the walk has to enter; the END record of the range leaves both loops
         TriFilter tf;
-        ps.enable = 0ull;
+        ps.enable = 0ull; ps.none = 1u;
         {
             const RayS ray = src.get();
             d3 xo, xd;
@@ -693,7 +697,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
             tri_filter_init(tf, xo, xd);
             if (prune && cur_xf == sc.prune_xf) {  // inner records carry boxes of THIS space only
                 const bool ok = strict_filter_init(ps.sf, xo, xd, sc);
-                ps.enable = clean & __builtin_amdgcn_ballot_w64(ok);
+                ps.enable = clean & __builtin_amdgcn_ballot_w64(ok); ps.none = (uint32_t)__builtin_amdgcn_readfirstlane(ps.enable == 0ull ? 1 : 0);
 #ifdef RT_TRACE_DIAG
                 cnt.diag_flags |= (active && !ok) ? 4u : 0u;
 #endif
@@ -719,7 +723,12 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
             if (cnt.leaf_open) cnt.cyc_leaf += c0 - cnt.leaf_open;
             cnt.leaf_open = (rec & RT_STREAM_KIND) ? c0 : 0;
 #endif
-            if (RT_LEAF_FIRST && MODE == BOX_PLAIN && !COUNT && (rec & RT_STREAM_KIND) == RT_STREAM_TRI2 && wword<8>(w) == cur_xf) {
+            // "a TRI2 leaf in the space the rays are in" as ONE integer test (made opaque to the optimiser, which would otherwise turn it back into
+            // two booleans and combine those as 64-bit lane masks: 10 scalar instructions instead of 5 on every step)
+            uint32_t not_leaf_here = ((rec & RT_STREAM_KIND) ^ RT_STREAM_TRI2) | (wword<8>(w) ^ cur_xf);
+            not_leaf_here = (uint32_t)__builtin_amdgcn_readfirstlane((int)not_leaf_here);   // wave-uniform by construction; a no-op where the compiler knows it
+            asm("" : "+s"(not_leaf_here));
+            if (RT_LEAF_FIRST && MODE == BOX_PLAIN && !COUNT && not_leaf_here == 0u) {
                 // Common leaf, rays already in its space: triangle filter FIRST.  The leaf's box only gates its own
                 // triangle tests (skip == next record either way), so it is evaluated for a wave only when some ray is
                 // not certainly rejected by both triangles -- the weak box test of the reference passes most leaves
@@ -729,7 +738,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
                 tri_filter(tf, w, rejA, rejB);
                 bool changed = false;
                 if ((m_act & ~(rejA & rejB)) != 0ull) {
-                    const lanemask m_pass = box_step<0, MODE, COUNT>(w, bf, ps, false, off, wait, rec, nodes, src, h, t_min, cnt);
+                    const lanemask m_pass = box_step<0, MODE, COUNT>(w, bf, ps, 1u, off, wait, rec, nodes, src, h, t_min, cnt);
                     if ((m_pass & ~(rejA & rejB)) != 0ull) changed = tri2_exact<COUNT, MODE>(sc, node, off, m_pass, rejA, rejB, src, cur_xf, h, t_min, inst_prim, bf, cnt);
                     RT_RECONVERGE();
                 }
@@ -737,7 +746,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
                 RT_SHADOW_FINISH(changed)
                 continue;
             }
-            lanemask m_pass = box_step<0, MODE, COUNT>(w, bf, ps, (rec & RT_STREAM_KIND) == RT_STREAM_INNER, off, wait, rec, nodes, src, h, t_min, cnt);
+            lanemask m_pass = box_step<0, MODE, COUNT>(w, bf, ps, rec & RT_STREAM_KIND, off, wait, rec, nodes, src, h, t_min, cnt);
             if (m_pass == 0ull) {
                 off = skip;
             } else if ((rec & RT_STREAM_KIND) == RT_STREAM_INNER) {
@@ -750,7 +759,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
                     cnt.steps += 1;
 #endif
                     cnt.wsteps += 1u;
-                    m_pass = box_step<16, MODE, COUNT>(w, bf, ps, true, off, wait, rec2, nodes, src, h, t_min, cnt);
+                    m_pass = box_step<16, MODE, COUNT>(w, bf, ps, 0u, off, wait, rec2, nodes, src, h, t_min, cnt);
                     off = m_pass == 0ull ? wword<22>(w) : off + RT_STREAM_REC_INNER;
                 }
             } else if ((rec & RT_STREAM_KIND) == RT_STREAM_SPH2) {  // one or two spheres: exact f64 test (shape.rs:93-121) on inline geometry
