@@ -629,6 +629,10 @@ RT_DEV bool tri2_exact(const SceneDev& sc, uint32_t node, uint32_t rec_off, lane
     return changed;
 }
 
+// a wave-uniform value pinned to an SGPR: every value the cursor is assigned goes through this, so that the loop-carried cursor stays scalar
+// (left to itself the compiler homes it in a VGPR: a v_mov per assignment, a v_cndmask per select and a v_readfirstlane per step)
+RT_DEV uint32_t scalar_u32(uint32_t x) { x = (uint32_t)__builtin_amdgcn_readfirstlane((int)x); asm("" : "+s"(x)); return x; }
+
 template <int LEVEL, bool COUNT, bool INST, int MODE, class RAYSRC, class HIT>
 RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src, HIT& h, bool active, double t_min,
                           uint32_t inst_prim, LaneCount& cnt) {
@@ -649,7 +653,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
                 wait = fin_ ? end_off : wait;                                                      \
                 const uint32_t nxt_ = wave_min_u32(wait);                                          \
                 if (nxt_ >= end_off) { want = RT_WALK_DONE; break; }                               \
-                off = nxt_ > off ? nxt_ : off;                                                     \
+                off = scalar_u32(nxt_ > off ? nxt_ : off);                                                   \
             }                                                                                      \
         }                                                                                          \
         RT_RECONVERGE();                                                                           \
@@ -659,7 +663,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
     uint32_t wait = active ? first : 0xFFFFFFFFu;
     // strict pruning: top-level walks of NaN-free rays in scenes that have a pruned space; the walk starts in that space
     const bool prune = LEVEL == 0 && MODE == BOX_PLAIN && sc.prune_on != 0u;
-    uint32_t off = first, cur_xf = prune ? sc.prune_xf : RT_NONE;
+    uint32_t off = scalar_u32(first), cur_xf = prune ? sc.prune_xf : RT_NONE;
     lanemask clean = 0ull;
     PruneState ps;
     ps.enable = 0ull; ps.none = 1u; ps.s0 = ps.s1 = ps.s2 = 0xFFFFFFFFu; ps.any_suspect = false;
@@ -711,7 +715,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
 #ifdef RT_TRACE_DIAG
             const uint64_t c0 = __builtin_readcyclecounter();
 #endif
-            off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);  // the nested walk / the per-lane certificate loop make the compiler class the (wave-uniform) cursor divergent
+            off = scalar_u32(off);
             window_issue(w, base, off);
             window_wait(w);
             const uint32_t skip = wword<6>(w), rec = wword<7>(w);
@@ -742,15 +746,15 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
                     if ((m_pass & ~(rejA & rejB)) != 0ull) changed = tri2_exact<COUNT, MODE>(sc, node, off, m_pass, rejA, rejB, src, cur_xf, h, t_min, inst_prim, bf, cnt);
                     RT_RECONVERGE();
                 }
-                off += RT_STREAM_REC_TRI2;
+                off = scalar_u32(off + RT_STREAM_REC_TRI2);
                 RT_SHADOW_FINISH(changed)
                 continue;
             }
             lanemask m_pass = box_step<0, MODE, COUNT>(w, bf, ps, rec & RT_STREAM_KIND, off, wait, rec, nodes, src, h, t_min, cnt);
             if (m_pass == 0ull) {
-                off = skip;
+                off = scalar_u32(skip);
             } else if ((rec & RT_STREAM_KIND) == RT_STREAM_INNER) {
-                off += RT_STREAM_REC_INNER;
+                off = scalar_u32(off + RT_STREAM_REC_INNER);
                 // the window already holds the next record's header: if that is an inner node too, take it in the same step
                 // (no load, no wait, no trip round the loop) -- a quarter of all steps on the pagoda before strict pruning
                 const uint32_t rec2 = wword<23>(w);
@@ -760,11 +764,11 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
 #endif
                     cnt.wsteps += 1u;
                     m_pass = box_step<16, MODE, COUNT>(w, bf, ps, 0u, off, wait, rec2, nodes, src, h, t_min, cnt);
-                    off = m_pass == 0ull ? wword<22>(w) : off + RT_STREAM_REC_INNER;
+                    off = scalar_u32(m_pass == 0ull ? wword<22>(w) : off + RT_STREAM_REC_INNER);
                 }
             } else if ((rec & RT_STREAM_KIND) == RT_STREAM_SPH2) {  // one or two spheres: exact f64 test (shape.rs:93-121) on inline geometry
                 // the spheres' own transform is applied on the spot: only the triangle filter needs the walk to BE in a space
-                off += RT_STREAM_REC_SPH2;
+                off = scalar_u32(off + RT_STREAM_REC_SPH2);
                 const uint32_t nsph = wword<9>(w);
                 const RayS ray = src.get();
                 d3 xo, xd;
@@ -792,7 +796,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
                     want = wword<8>(w);
                     break;
                 }
-                off += RT_STREAM_REC_TRI2;
+                off = scalar_u32(off + RT_STREAM_REC_TRI2);
                 if (COUNT) {  // reference-order test count: two triangles, or one (tested twice as the duplicated child of a 1-object BVH leaf)
                     const uint32_t ntests = (nodes[node].prim1 != RT_NONE || (rec & RT_NODE_DUP_RIGHT)) ? 2u : 1u;
                     cnt.tri += mask_lane(m_pass) ? ntests : 0u;
@@ -810,7 +814,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
                 const uint32_t p0 = wword<8>(w), p1 = wword<9>(w);
                 const bool pass = mask_lane(m_pass);
                 const uint32_t x0 = wword<10>(w);  // transform of the first primitive, applied on the spot
-                off += RT_STREAM_REC_LEAF;
+                off = scalar_u32(off + RT_STREAM_REC_LEAF);
                 const GeomS g0 = load_geom(geom, p0);
                 const RayS ray = src.get();
                 d3 xo, xd;
