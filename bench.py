@@ -37,6 +37,7 @@ WORKLOADS = {
     "random_spheres_400x225_mis": ("random", False, 400, 225, 0, 50),  # configs[0]
     "earth_1080p_brdf": ("simple", False, 1920, 1080, 2, 5),       # configs[3]
     "broken_cube_4k_mis": ("simple_triangle", False, 3840, 2160, 0, 5),  # configs[4]
+    "cornell_4k_mis": ("cornell", False, 3840, 2160, 0, 5),             # configs[4], its other scene: six instanced cubes (main.rs:92-211)
 }
 INTEGRATOR_NAMES = ["mis", "light_is", "brdf", "uniform"]
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s

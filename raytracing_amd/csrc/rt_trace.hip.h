@@ -871,6 +871,9 @@ RT_DEV void traverse(const SceneDev& sc, uint32_t first, const RAYSRC& src, HIT&
 #ifndef RT_TRACE_WAVES
 #define RT_TRACE_WAVES 6  /* waves per SIMD the register allocator must leave room for */
 #endif
+#ifndef RT_TRACE_WAVES_INST
+#define RT_TRACE_WAVES_INST 4   /* scenes with instances (cornell): the nested sub-walk doubles the live state (168 VGPRs left alone); measured at 4K MIS: 2 / 3 / 4 / 5 / 6 waves = 1 711 / 2 111 / 2 165 / 1 516 / 1 458 Mrays/s */
+#endif
 #ifndef RT_TRACE_WAVES_REGS
 #define RT_TRACE_WAVES_REGS 3
 #endif
@@ -879,7 +882,7 @@ RT_DEV void traverse(const SceneDev& sc, uint32_t first, const RAYSRC& src, HIT&
 // (almost) every leaf step runs an exact f64 test and would read the ray back from LDS each time.
 // SHADOW: the rays are MIS visibility rays whose block carries t_light in its last slot; see RayFromLdsT.
 template <bool COUNT, bool INST, bool REGS, bool SHADOW = false>
-__global__ __launch_bounds__(RT_TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(INST ? 2 : REGS ? RT_TRACE_WAVES_REGS : RT_TRACE_WAVES))) void k_trace(SceneDev sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_fixed,
+__global__ __launch_bounds__(RT_TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(INST ? RT_TRACE_WAVES_INST : REGS ? RT_TRACE_WAVES_REGS : RT_TRACE_WAVES))) void k_trace(SceneDev sc, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_fixed,
                                                const double* __restrict__ rays, uint32_t cap, double t_min, double t_max,
                                                uint32_t* __restrict__ out_prim, uint32_t* __restrict__ out_inst, double* __restrict__ out_t,
                                                unsigned long long* __restrict__ stats, uint32_t lanes, uint32_t t_stride, PathHit* __restrict__ out_hit,
