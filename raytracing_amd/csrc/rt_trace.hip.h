@@ -875,7 +875,7 @@ RT_DEV void traverse(const SceneDev& sc, uint32_t first, const RAYSRC& src, HIT&
 #define RT_TRACE_WAVES_INST 4   /* scenes with instances (cornell): the nested sub-walk doubles the live state (168 VGPRs left alone); measured at 4K MIS: 2 / 3 / 4 / 5 / 6 waves = 1 711 / 2 111 / 2 165 / 1 516 / 1 458 Mrays/s */
 #endif
 #ifndef RT_TRACE_WAVES_REGS
-#define RT_TRACE_WAVES_REGS 3
+#define RT_TRACE_WAVES_REGS 4   /* 128 VGPRs + 88 B of scratch; 3 / 4 / 5 waves: earth 6 455 / 6 717 / 6 818, random spheres 2 188 / 2 296 / 2 095, broken cube 6 900 / 6 983 / 6 867 Mrays/s */
 #endif
 // rays: one 64-byte block per path (ox,oy,oz,dx | dy,dz,time,pad); outputs indexed by path.
 // REGS: keep the f64 ray in registers instead of LDS -- for scenes whose leaves are mostly not triangles, where
