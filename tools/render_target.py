@@ -31,7 +31,7 @@ except Exception:
     rt.write_png(out + ".png", img)
 a = acc.cpu().numpy()
 stats = {"scene": "mesh (pagoda OBJ, Lambertian 0.5, two sphere lights, checker ground)", "width": W, "height": H, "integrator": "mis", "max_depth": depth,
-         "spp": spp, "spp_per_call": per_call, "seed": 0x5EED, "bvh_seed": 3, "seconds": dt, "rays": rays, "paths": paths, "mrays_per_s": rays / dt / 1e6,
+         "spp": spp, "spp_per_call": per_call, "seed": 0x5EED, "bvh_seed": 3, "bvh_axis": os.environ.get("RT_BVH_AXIS", "min_area"), "seconds": dt, "rays": rays, "paths": paths, "mrays_per_s": rays / dt / 1e6,
          "paths_per_s": paths / dt, "mean_radiance": [float(x) for x in a.reshape(-1, 3).mean(0) / spp], "nan_pixels": int(np.isnan(a).any(axis=2).sum()),
          "accum_checksum": float(a.astype(np.float64).sum())}
 json.dump(stats, open(out + ".json", "w"), indent=1)

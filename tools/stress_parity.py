@@ -6,7 +6,7 @@ import numpy as np
 import oracle_ffi as orc
 import raytracing_amd as rt
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
-hs = rt.HostScene.builtin("mesh", bvh_seed=3)
+hs = rt.HostScene.builtin("mesh", bvh_seed=3, bvh_axis=os.environ.get("RT_BVH_AXIS", "min_area"))
 osc = orc.OracleScene(hs.describe())
 ctx = rt.Context(0); gs = ctx.upload(hs)
 geo = hs.geoms(); tri = geo[geo["kind"] == 0]["d"]
