@@ -3,18 +3,23 @@
 (`MultipleImportanceSampleIntegrator`, integrator.rs:31-171 -- the one the reference's main() selects), depth 5
 (main.rs:944), 1000 spp = configs[2], which fits one GPU.
 
-A "step" is one render call (ray-gen -> [traverse -> shade -> traverse shadow rays] x depth -> unwind -> accumulate)
-over --spp-per-step samples of every pixel; the default 50 makes the driver's `--steps 20` exactly the 1000-spp frame.
-Steps are queued with rt_render_begin and waited for with rt_render_end, two in flight (one 50-spp pass each, on the scene's
-two lanes): the thin deep bounces of one step overlap the next step's kernels; --sync-steps runs blocking rt_render calls
-(two lanes of 25-spp passes inside each call) instead.  Inputs (the flattened scene) are resident in HBM before the timed region;
-accumulators stay on the device.  N ranks: `--scaling weak` (default) gives every rank its own disjoint range of
-steps x spp_per_step absolute sample indices; `--scaling strong` splits each step's samples across the ranks
-(distributed.spp_range).  One broadcast of the scene bytes before, one all-reduce of the fp32 sums inside the timed region.
+A "step" is --spp-per-step samples of every pixel (ray-gen -> [traverse -> shade -> traverse shadow rays] x depth -> unwind ->
+accumulate); the default 50 makes the driver's `--steps 20` exactly the 1000-spp frame, and ms_per_step = time / steps.
+The samples are rendered as JOBS queued with rt_render_begin and waited for with rt_render_end, two in flight (one pass each, on
+the scene's two lanes): the thin deep bounces of one job overlap the other job's kernels; --sync-steps runs blocking rt_render
+calls (two lanes of half-size passes inside each call) instead.  Inputs (the flattened scene) are resident in HBM before the timed
+region; accumulators stay on the device.
+
+N ranks (main.rs:1009-1011: tonemap after the sum): `--scaling strong` (default) renders THE frame -- the
+steps x spp_per_step absolute sample indices [0, S) -- split as contiguous per-rank ranges [floor(S r/N), floor(S (r+1)/N));
+every rank cuts its range into jobs of at least spp_per_step samples (125 spp on 8 ranks = 2 jobs of 62 and 63), so job size
+does not shrink with N.  `--scaling weak` gives every rank its own S samples (rank r: [S r, S (r+1))).  One broadcast of the
+scene bytes before, one all-reduce of the fp32 sums inside the timed region (reported separately as allreduce_ms).
 
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (child processes,
-before this process touches the GPU); under `torch.distributed.run` it is one of the ranks.  n_gpus in the line is the
-live world size and must equal --gpus.
+before this process touches the GPU), polls them all, and on the first rank that exits non-zero terminates the others and
+returns non-zero; every rank's stderr is kept and relayed.  Under `torch.distributed.run` it is one of the ranks.  n_gpus in
+the line is the live world size and must equal --gpus.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
@@ -57,9 +62,11 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="pagoda_1080p_mis", choices=sorted(WORKLOADS))
     ap.add_argument("--spp-per-step", type=int, default=50)       # x the driver's 20 steps = the 1000 spp of the metric
-    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
+    # strong (default): the frame of steps x spp_per_step samples, split over the ranks as contiguous sample ranges;
+    # weak: every rank renders steps x spp_per_step samples of its own.  The same thing on one rank.
+    ap.add_argument("--scaling", default="strong", choices=("weak", "strong"))
     ap.add_argument("--one-lane", action="store_true")            # A/B: the passes of a call one after the other
-    ap.add_argument("--sync-steps", action="store_true")          # A/B: every step a blocking rt_render (two lanes inside the call) instead of two steps in flight
+    ap.add_argument("--sync-steps", action="store_true")          # A/B: every job a blocking rt_render (two lanes inside the call) instead of two jobs in flight
     ap.add_argument("--bvh-seed", type=int, default=3)
     # bvh.rs:53 draws every split axis from an unseeded RNG, so the reference's tree differs from run to run and every axis assignment is
     # one of its trees.  min_area (default): per node the axis, of those three, whose median split has the least area x count
@@ -70,30 +77,96 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"))  # gloo + --renderer: the CPU test of the N-rank plumbing
     ap.add_argument("--renderer", default="")                     # python file with make_renderer(args, rank, world, device, distributed_module): replaces the HIP renderer (tests)
+    # rehearsal on ONE GPU of what rank r of an N-rank run does: "r/N" -> this process renders rank r's share of the frame (same jobs,
+    # same sample indices), with no process group; the line then carries `rehearsal` and is not a scaling measurement
+    ap.add_argument("--rehearse-rank", default="")
     return ap.parse_args(argv)
+
+
+def plan_jobs(b, e, job_spp):
+    """Cuts the sample range [b, e) into max(1, (e-b) // job_spp) contiguous jobs of near-equal size: every job has at least
+    job_spp samples (unless the whole range is smaller), so the per-launch ray counts do not shrink with the number of ranks."""
+    n = e - b
+    if n <= 0:
+        return []
+    k = max(1, n // max(job_spp, 1))
+    return [(b + (i * n) // k, b + ((i + 1) * n) // k) for i in range(k)]
+
+
+def rank_range(scaling, rank, world, frame_spp):
+    """Absolute sample indices of rank `rank`: strong -- its contiguous share of the frame [0, frame_spp) (distributed.spp_range);
+    weak -- a frame of its own."""
+    if scaling == "weak":
+        return rank * frame_spp, (rank + 1) * frame_spp
+    return (rank * frame_spp) // world, ((rank + 1) * frame_spp) // world
 
 
 def spawn_ranks(args):
     """--gpus N without a launcher: start N ranks of this script as child processes.  Runs BEFORE anything here touches
-    the GPU (torch is not even imported yet), and nothing is exec'ed in place."""
+    the GPU (torch is not even imported yet), and nothing is exec'ed in place.  All children are polled: the first one that
+    exits non-zero ends the run -- its siblings (which would otherwise sit in a collective until some time limit) are
+    terminated, by the PIDs started here, and the exit code is non-zero.  stdout and stderr of every rank are kept."""
+    import signal
+    import tempfile
+    signal.signal(signal.SIGTERM, lambda *a: sys.exit(143))   # so that the `finally` below ends the ranks when this parent is told to stop
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    codes = [p.wait() for p in procs]
-    lines = [ln for ln in (out or "").splitlines() if ln.startswith("{")]
-    if lines:
-        print(lines[-1], flush=True)
+    tmp = tempfile.mkdtemp(prefix="rt_bench_ranks_")
+    procs, files = [], []
+    try:
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            fo, fe = open(os.path.join(tmp, f"rank{r}.out"), "w+"), open(os.path.join(tmp, f"rank{r}.err"), "w+")
+            files.append((fo, fe))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=fo, stderr=fe, text=True))
+        codes = [None] * len(procs)
+        first_bad = None
+        while any(c is None for c in codes) and first_bad is None:
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    codes[r] = p.poll()
+                    if codes[r] not in (None, 0) and first_bad is None:
+                        first_bad = r
+            if first_bad is None:
+                time.sleep(0.05)
+        if first_bad is not None:   # fail fast: nobody waits for a rank that is gone
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    p.terminate()
+            deadline = time.time() + 10.0
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    try:
+                        codes[r] = p.wait(timeout=max(0.1, deadline - time.time()))
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[r] = p.wait()
+    finally:
+        for p in procs:   # an exception / signal in this parent must not leave ranks behind
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+    outs = []
+    for r, (fo, fe) in enumerate(files):
+        fo.seek(0); fe.seek(0)
+        outs.append(fo.read())
+        err = fe.read()
+        for ln in err.splitlines():
+            print(f"[rank {r}] {ln}", file=sys.stderr)
+        for ln in (outs[r].splitlines() if r else []):   # only rank 0's stdout carries the line; anything a sibling printed is kept too
+            print(f"[rank {r} stdout] {ln}", file=sys.stderr)
+        fo.close(); fe.close()
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    lines = [ln for ln in outs[0].splitlines() if ln.startswith("{")]
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad or not lines:
-        print(f"bench.py: ranks failed (rank, exit code): {bad}; JSON lines from rank 0: {len(lines)}", file=sys.stderr)
+        what = f"rank {first_bad} exited with code {codes[first_bad]} first; the other ranks were terminated" if first_bad is not None else "no JSON line from rank 0"
+        print(f"bench.py: {what} (rank, exit code): {bad}", file=sys.stderr)
         return 1
+    print(lines[-1], flush=True)
     return 0
 
 
@@ -118,8 +191,14 @@ class HipRenderer:
                               flags=self.flags | flags).as_dict()
 
     # rt_render_begin / rt_render_end: the call is queued on one of the scene's two lanes; two calls may be in flight
-    def begin(self, accum, b, e):
-        return self.gs.render_begin(accum.data_ptr(), self.W, self.H, b, e, self.depth, self.integrator, seed=0x5EED, flags=self.flags)
+    def begin(self, accum, b, e, samples_per_pass=0):
+        return self.gs.render_begin(accum.data_ptr(), self.W, self.H, b, e, self.depth, self.integrator, seed=0x5EED, samples_per_pass=samples_per_pass,
+                                    flags=self.flags)
+
+    def pass_size_for(self, n_spp):
+        """A job of n_spp samples runs as ONE pass when its path state (depth x 96 B of bounce records + 320 B per path) fits 112 GiB per
+        lane (two lanes + scene + certificate tables stay under the 288 GB); otherwise the library's default pass size (0)."""
+        return n_spp if n_spp * self.W * self.H * (self.depth * 96 + 320) <= (112 << 30) and n_spp * self.W * self.H < (128 << 20) else 0
 
     def end(self, job):
         return self.gs.render_end(job).as_dict()
@@ -156,6 +235,15 @@ def main():
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.spp_per_step < 1:
         print("bench.py: --gpus/--steps/--spp-per-step must be >= 1", file=sys.stderr)
         return 2
+    rehearse = None
+    if args.rehearse_rank:
+        try:
+            rr, rn = (int(x) for x in args.rehearse_rank.split("/"))
+            assert 0 <= rr < rn and args.gpus == 1
+        except Exception:
+            print("bench.py: --rehearse-rank wants r/N with 0 <= r < N, and --gpus 1", file=sys.stderr)
+            return 2
+        rehearse = (rr, rn)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args)
 
@@ -193,47 +281,49 @@ def main():
         R = HipRenderer(args, rank, world, local_rank, dev, rtd)
     accum = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     spp_step = args.spp_per_step
-    total_steps = args.warmup + args.steps
-
-    def step_range(i):
-        if args.scaling == "weak":   # rank r owns the absolute sample indices [r*total_steps*spp_step, (r+1)*total_steps*spp_step)
-            b = (rank * total_steps + i) * spp_step
-            return b, b + spp_step
-        return rtd.spp_range(rank, world, spp_step, i * spp_step)   # strong: step i = samples [i*spp_step, (i+1)*spp_step) split over the ranks
+    frame_spp = args.steps * spp_step                      # the frame: absolute sample indices [0, frame_spp)
+    shard_rank, shard_world = rehearse if rehearse else (rank, world)
+    my_b, my_e = rank_range(args.scaling, shard_rank, shard_world, frame_spp)
+    jobs = plan_jobs(my_b, my_e, spp_step)                 # this rank's share as jobs of >= spp_per_step samples
+    pass_size = getattr(R, "pass_size_for", lambda n: 0)
+    # warm-up: `--warmup` jobs of this rank's largest job size (so the path buffers the timed jobs need exist), on sample indices past
+    # every rank's share; their sums are thrown away
+    big = max((e - b for b, e in jobs), default=spp_step)
+    warm_first = max(shard_world, 1) * frame_spp
+    warm_jobs = [(warm_first + i * big, warm_first + (i + 1) * big) for i in range(args.warmup)]
 
     pipelined = hasattr(R, "begin") and not args.sync_steps and not args.one_lane
 
-    def run_steps(first, count):
-        """`count` steps; pipelined: steps are queued two at a time (rt_render_begin x2, then rt_render_end x2), one 50-spp pass each
-        on the scene's two lanes, so the thin deep bounces of one step overlap the other step's.  Begun TOGETHER on purpose: two steps
-        in the same phase measured 6 % faster than a staggered pair (a thin launch queued behind the other step's full-machine
-        launch waits for it).  Every step still adds its sums after the step before it."""
+    def run_jobs(todo):
+        """Renders the sample ranges of `todo` in order.  Pipelined: two jobs in flight (rt_render_begin / rt_render_end, one pass each on the
+        scene's two lanes), the next one begun as soon as the oldest has ended, so the thin deep bounces of one job overlap the other job's
+        kernels and an odd job count leaves no lane idle for a whole job.  Every job still adds its sums after the job begun before it."""
         out, pending = [], []
-        for i in range(first, first + count):
-            b, e = step_range(i)
-            if e <= b:
-                continue
+        for b, e in todo:
             if pipelined:
-                pending.append(R.begin(accum, b, e))
                 if len(pending) == 2:
-                    out += [R.end(pending.pop(0)), R.end(pending.pop(0))]
+                    out.append(R.end(pending.pop(0)))
+                pending.append(R.begin(accum, b, e, samples_per_pass=pass_size(e - b)))
             else:
-                out.append(R.render(accum, b, e))
+                out.append(R.render(accum, b, e, samples_per_pass=pass_size(e - b)))
         while pending:
             out.append(R.end(pending.pop(0)))
         return out
 
     sync()
-    run_steps(0, args.warmup)
+    run_jobs(warm_jobs)
     accum.zero_()
     sync()
     if world > 1:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
-    stats = run_steps(args.warmup, args.steps)
+    stats = run_jobs(jobs)
+    sync()
+    t_render = time.perf_counter() - t0
     rtd.allreduce_accum(accum)
     sync()
+    t_allreduce = time.perf_counter() - t0 - t_render
     if world > 1:
         dist.barrier()
     sync()
@@ -241,42 +331,56 @@ def main():
 
     rays = sum(s["rays"] for s in stats)
     paths = sum(s["paths"] for s in stats)
-    tot = torch.tensor([float(rays), float(paths), dt], dtype=torch.float64, device=dev)
+    mine = torch.tensor([float(rays), float(paths), dt, t_render, t_allreduce, float(my_e - my_b)], dtype=torch.float64, device=dev)
     if world > 1:
-        sums = tot.clone(); dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-        mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        rays_all, paths_all, t_max = float(sums[0]), float(sums[1]), float(mx[2])
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        every = torch.stack(every).cpu()
     else:
-        rays_all, paths_all, t_max = float(rays), float(paths), dt
-    spp_total = args.steps * spp_step * (world if args.scaling == "weak" else 1)
-
-    rc = 0
-    if rank == 0:
-        out = {
-            "metric": "Mrays/s", "value": rays_all / t_max / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": t_max / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic (reference pagoda OBJ asset, Lambertian 0.5 albedo; Philox-seeded camera samples)",
-            "config": {"workload": args.workload, "scene": scene, "width": W, "height": H, "integrator": INTEGRATOR_NAMES[integrator],
-                       "max_depth": depth, "spp_per_step": spp_step, "render_lanes": 1 if args.one_lane else 2, "spp_total": spp_total,
-                       "steps_in_flight": 2 if pipelined else 1,
-                       "sharding": f"spp-range x{world}" if world > 1 else "none", "bvh_seed": args.bvh_seed, "bvh_axis": args.bvh_axis},
-            "paths_per_s": paths_all / t_max, "rays": rays_all, "paths": paths_all,
-            "accum_checksum": float(accum.double().sum()),
-        }
-        if not args.renderer:
-            out.update(report_kernels(args, R, accum, stats, step_range, rays, spp_step))
-            if world == 1 and not args.no_cpu_baseline:
-                threads = args.cpu_threads or min(16, os.cpu_count() or 1)
-                out["cpu_baseline"] = cpu_baseline(R.desc, integrator, depth, threads)
-    R.close()
-    if rank == 0:
-        if world == 1 and not args.renderer and args.bvh_axis != "seeded" and not args.no_seeded_compare:
-            out["seeded_tree"] = seeded_compare(args, local_rank, dev, rtd, accum, sync, spp_step)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        every = mine.cpu().reshape(1, -1)
+    rays_all, paths_all, t_max = float(every[:, 0].sum()), float(every[:, 1].sum()), float(every[:, 2].max())
+    spp_total = int(every[:, 5].sum())
+    checksum = float(accum.double().sum())
+    if world > 1:   # the ranks part here: what rank 0 measures beside the line (one-lane step, counting pass, CPU baseline) is its own business
         dist.barrier()
         dist.destroy_process_group()
-    return rc
+    if rank != 0:
+        R.close()
+        return 0
+
+    per_rank_rate = [float(every[r, 0] / max(float(every[r, 3]), 1e-12) / 1e6) for r in range(world)]
+    out = {
+        "metric": "Mrays/s", "value": rays_all / t_max / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": t_max / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic (reference pagoda OBJ asset, Lambertian 0.5 albedo; Philox-seeded camera samples)",
+        "config": {"workload": args.workload, "scene": scene, "width": W, "height": H, "integrator": INTEGRATOR_NAMES[integrator],
+                   "max_depth": depth, "spp_per_step": spp_step, "render_lanes": 1 if args.one_lane else 2, "spp_total": spp_total,
+                   "frame_spp": frame_spp, "jobs_in_flight": 2 if pipelined else 1,
+                   "sharding": ("none" if world == 1 else
+                                f"spp-range x{world}: rank r renders samples [floor({frame_spp}r/{world}), floor({frame_spp}(r+1)/{world})) of the frame, as jobs of >= {spp_step} spp"
+                                if args.scaling == "strong" else
+                                f"spp-range x{world}: rank r renders samples [{frame_spp}r, {frame_spp}(r+1)), as jobs of >= {spp_step} spp"),
+                   "per_rank_spp": [int(v) for v in every[:, 5]], "rank0_jobs_spp": [e - b for b, e in jobs],
+                   "bvh_seed": args.bvh_seed, "bvh_axis": args.bvh_axis},
+        "paths_per_s": paths_all / t_max, "rays": rays_all, "paths": paths_all,
+        "render_ms": {"min": float(every[:, 3].min()) * 1e3, "max": float(every[:, 3].max()) * 1e3},
+        "allreduce_ms": float(every[:, 4].max()) * 1e3,     # slowest rank: sum of the fp32 accumulators (W x H x 3), inside the timed region
+        "per_rank_mrays_s": {"min": min(per_rank_rate), "max": max(per_rank_rate)},
+        "accum_checksum": checksum,
+    }
+    if rehearse:
+        out["rehearsal"] = {"rank": rehearse[0], "world": rehearse[1],
+                            "note": "ONE GPU rendering the share rank r of an N-rank run would render (same jobs, same sample indices); no collective ran"}
+    if not args.renderer:
+        out.update(report_kernels(args, R, accum, stats, jobs, rays))
+        if not args.no_cpu_baseline:   # on rank 0's host cores, after the ranks have parted
+            threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(R.desc, integrator, depth, threads)
+    R.close()
+    if world == 1 and not rehearse and not args.renderer and args.bvh_axis != "seeded" and not args.no_seeded_compare:
+        out["seeded_tree"] = seeded_compare(args, local_rank, dev, rtd, accum, sync, spp_step)
+    print(json.dumps(out), flush=True)
+    return 0
 
 
 def seeded_compare(args, local_rank, dev, rtd, accum, sync, spp_step):
@@ -299,12 +403,12 @@ def seeded_compare(args, local_rank, dev, rtd, accum, sync, spp_step):
             "note": "same workload on the tree built from the seeded axis stream; untimed extra, not part of `value`"}
 
 
-def report_kernels(args, R, accum, stats, step_range, rays, spp_step):
+def report_kernels(args, R, accum, stats, jobs, rays):
     """rank 0, after the timed region: per-kernel times of the timed steps, the roofline of the dominant kernel (k_trace),
     and two untimed extra renders -- one step on ONE lane (launch durations without the other lane's kernels sharing the
     machine) and a 1-spp pass of the counting kernel (reference-order test counts: what the traversal replaces)."""
     rt = R.rt
-    b, e = step_range(args.warmup)
+    b, e = jobs[0]
     alone = R.render(accum, b, e, flags=rt.RENDER_ONE_LANE, samples_per_pass=stats[0]["samples_per_pass"] if stats else 0)
     # the waves' record steps come from a step of their own: the counter is one same-address atomic per wave (5 % of the frame), so neither the
     # timed steps nor the one-lane step above run with it
@@ -348,6 +452,9 @@ def report_kernels(args, R, accum, stats, step_range, rays, spp_step):
         "samples_per_pass": stats[0]["samples_per_pass"] if stats else None,
         "roofline": {"kernel": "k_trace<false, false, false>", "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                     # `achieved` prices every 136-B stream window as if it came from HBM although most are served by the scalar cache / L2;
+                     # measured_frac is the PMC-measured L2-miss traffic of the same launches (one lane) over their duration, / peak -- the HBM rate proper
+                     "measured_frac": pmc.get("measured_hbm_frac"), "limiter": "instruction issue x lane use, not bandwidth (issue_pmc)",
                      "algorithmic_bytes_per_ray": bytes_per_ray, "algorithmic_bytes_per_ray_parts": per_ray,
                      "rays_per_launch": rays_per_launch, "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
                      "shadow": {"launches": shadow_launches, "rays": shadow_rays, "avg_launch_ms": ms_shadow / max(shadow_launches, 1)},
@@ -359,7 +466,7 @@ def report_kernels(args, R, accum, stats, step_range, rays, spp_step):
                                   "frac": bytes_per_ray * alone["rays"] / max(alone["ms_trace"], 1e-9) / 1e6 / HBM_PEAK_GBS},
                      "issue_pmc": pmc,
                      "executed": {"record_steps_per_ray": wave_steps / max(rays, 1), "record_steps_per_wave": 64.0 * wave_steps / max(rays, 1)},
-                     "note": "achieved = algorithmic bytes the production kernel moves per launch (queue entry, ray block, hit record, certificate list, 136-B stream "
+                     "note": "achieved = algorithmic bytes incl. cache-served re-reads: what the production kernel moves per launch (queue entry, ray block, hit record, certificate list, 136-B stream "
                              "window per record step of a wave -- the step count comes from the kernel) / average k_trace launch duration by HIP events over the "
                              "timed region; traffic = measured L2-miss bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/); the kernel is bound by "
                              "instruction issue and lane use, not by HBM (issue_pmc)"},

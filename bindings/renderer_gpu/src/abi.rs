@@ -264,6 +264,7 @@ extern "C" {
     pub fn rt_capture_rays(scene: *mut rt_scene, params: *const rt_render_params, bounce: u32, shadow: c_int, stride: u32, max_n: u32, n_out: *mut u32, queue_len: *mut u32,
                            rays: *mut f64, prim_id: *mut u32, inst_id: *mut u32, t: *mut f64, t_light: *mut f64) -> c_int;
     pub fn rt_accum_zero(ctx: *mut rt_context, accum_dev: *mut f32, width: u32, height: u32) -> c_int;
+    pub fn rt_scene_set_pass_budget(scene: *mut rt_scene, bytes_per_lane: u64) -> c_int;
     pub fn rt_render_host(scene: *mut rt_scene, params: *const rt_render_params, accum_host: *mut f32, stats: *mut rt_stats) -> c_int;
     pub fn rt_resolve(ctx: *mut rt_context, accum_dev: *const f32, width: u32, height: u32, spp: u32, tonemap: c_int, out_dev: *mut f32) -> c_int;
     pub fn rt_resolve_host(accum_host: *const f32, width: u32, height: u32, spp: u32, tonemap: c_int, out_host: *mut f32) -> c_int;

@@ -55,6 +55,13 @@ impl GpuRenderer {
         Ok(GpuRenderer { ctx, scene: gs })
     }
 
+    /// Bytes of path state per render lane that `render` may use (default 80 GiB per lane, two lanes).  On a GPU that other work
+    /// occupies in part the library steps the budget down by itself when an allocation fails; a caller that wants resumed or
+    /// sharded renders to cut the same passes sets it once, before the first render.
+    pub fn set_pass_budget(&self, bytes_per_lane: u64) -> Result<(), GpuError> {
+        unsafe { check(rt_scene_set_pass_budget(self.scene, bytes_per_lane)) }
+    }
+
     /// Radiance SUMS of the absolute sample indices [spp_begin, spp_end) for every pixel (row 0 = bottom row), fp32.
     /// Ranks of a multi-GPU render call this with disjoint ranges and add the results before `resolve`.
     pub fn render_sums(&self, integrator: i32, width: u32, height: u32, spp_begin: u32, spp_end: u32, max_depth: i32, seed: u64) -> Result<(Vec<f32>, rt_stats), GpuError> {

@@ -161,10 +161,12 @@ typedef struct rt_render_params {
     int32_t max_depth;           /* main.rs:944 */
     int32_t integrator;          /* RT_INT_* */
     uint64_t seed;               /* Philox key; counter = (pixel, sample, level, block) */
-    uint32_t samples_per_pass;   /* 0 = library default, a pure function of (width*height, max_depth, spp_end - spp_begin): 80 GiB of path state,
-                                  * 128M paths, half the call's samples, whichever is smallest -- never of free memory or call history, because
-                                  * pass boundaries fix the order of the fp32 sums.  Paths in flight = width*height*samples_per_pass per lane; a call
-                                  * of two or more passes runs two passes at a time on two streams */
+    uint32_t samples_per_pass;   /* 0 = library default, a pure function of (width*height, max_depth, spp_end - spp_begin) and the scene's pass
+                                  * budget (rt_scene_set_pass_budget, 80 GiB of path state per lane): budget, 128M paths, half the call's samples,
+                                  * whichever is smallest -- pass boundaries fix the order of the fp32 sums.  If the buffers do not fit, the budget
+                                  * is halved (at most five times, and it stays lowered for the scene) and the call renders in smaller passes;
+                                  * rt_stats.samples_per_pass reports the size used.  Paths in flight = width*height*samples_per_pass per lane; a
+                                  * call of two or more passes runs two passes at a time on two streams */
     uint32_t flags;              /* RT_RENDER_* */
 } rt_render_params;
 #define RT_RENDER_COUNT_TESTS 1u /* also count box/primitive tests (slower kernel variant) */
@@ -201,7 +203,7 @@ typedef struct rt_stats {
     double ms_trace_shadow;          /* the part of ms_trace spent in launches over MIS shadow rays (integrator.rs:82) */
     uint64_t trace_shadow_launches;  /* the part of trace_launches that traced shadow rays */
     uint64_t shadow_rays;            /* the part of `rays` that were shadow rays */
-    uint32_t samples_per_pass;       /* pass size the call used (a pure function of the parameters when samples_per_pass == 0) */
+    uint32_t samples_per_pass;       /* pass size the call used (samples_per_pass == 0: a pure function of the parameters and the scene's pass budget) */
     uint32_t lanes;                  /* render lanes the call used (1 or 2) */
     uint64_t walk_run_steps;         /* per-lane walk (k_walk): records visited, summed over rays (one 64-byte fetch each) */
     uint64_t walk_tri_steps;         /* ... triangle-leaf visits (144 bytes each) */
@@ -276,6 +278,10 @@ int rt_primary_rays(rt_scene* scene, uint32_t width, uint32_t height, uint32_t s
  * all-reduce(sum) their accumulators before rt_resolve.  Synchronous: returns when accum is final. */
 int rt_render(rt_scene* scene, const rt_render_params* params, float* accum_dev, rt_stats* stats);
 int rt_accum_zero(rt_context* ctx, float* accum_dev, uint32_t width, uint32_t height);
+/* Bytes of path state per render lane that a call with samples_per_pass == 0 may use (0 restores the default, 80 GiB: two lanes,
+ * the scene and its certificate tables fit 288 GB).  A renderer that shares its GPU sets it once, before the first render, so that
+ * every call -- also resumed and sharded ones -- cuts the same passes.  No counterpart in the reference (it renders pixel by pixel). */
+int rt_scene_set_pass_budget(rt_scene* scene, uint64_t bytes_per_lane);
 /* rt_render split in two, so that consecutive calls overlap on the GPU (the thin deep bounces of one call leave the machine part-idle;
  * the next call's kernels fill it -- what the two lanes do INSIDE one rt_render, without halving the pass size).  rt_render_begin
  * queues the call on one of the scene's two lanes (own stream, own path buffers, a host thread for the per-bounce readbacks) and

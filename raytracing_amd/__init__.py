@@ -245,6 +245,10 @@ class GpuScene:
         _hip_check(_ffi.hip().rt_render(self._h, C.byref(p), C.c_void_p(accum_ptr), C.byref(st)))
         return st
 
+    def set_pass_budget(self, bytes_per_lane):
+        """Bytes of path state per lane that samples_per_pass=0 may use (0 = default, 80 GiB)."""
+        _hip_check(_ffi.hip().rt_scene_set_pass_budget(self._h, int(bytes_per_lane)))
+
     def render_begin(self, accum_ptr, width, height, spp_begin, spp_end, max_depth, integrator, seed=0x5EED, samples_per_pass=0, flags=0):
         """rt_render_begin: queues the call (at most two in flight per scene) and returns a job handle for render_end."""
         p = self._params(width, height, spp_begin, spp_end, max_depth, integrator, seed, samples_per_pass, flags)

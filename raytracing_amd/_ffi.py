@@ -119,6 +119,7 @@ def hip():
         L.rt_render_end.argtypes = [C.c_void_p, P(Stats)]
         L.rt_capture_rays.argtypes = [C.c_void_p, P(RenderParams), u32, C.c_int, u32, u32, P(u32), P(u32), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_accum_zero.argtypes = [C.c_void_p, C.c_void_p, u32, u32]
+        L.rt_scene_set_pass_budget.argtypes = [C.c_void_p, u64]
         L.rt_render_host.argtypes = [C.c_void_p, P(RenderParams), C.c_void_p, P(Stats)]
         L.rt_resolve.argtypes = [C.c_void_p, C.c_void_p, u32, u32, u32, C.c_int, C.c_void_p]
         L.rt_resolve_host.argtypes = [C.c_void_p, u32, u32, u32, C.c_int, C.c_void_p]
@@ -132,7 +133,7 @@ def hip():
 
 ABI_SYMBOLS = ["rt_device_count", "rt_context_create", "rt_context_destroy", "rt_context_synchronize", "rt_scene_upload",
                "rt_scene_destroy", "rt_stream_build_host", "rt_stream_build_prod_host", "rt_prune_info_host", "rt_trace_closest", "rt_trace_closest_device", "rt_trace_closest_device_noalloc", "rt_primary_rays", "rt_render", "rt_render_begin", "rt_render_end", "rt_capture_rays",
-               "rt_accum_zero", "rt_render_host", "rt_resolve", "rt_resolve_host", "rt_sample_radiance", "rt_sample_radiance_sig",
+               "rt_accum_zero", "rt_scene_set_pass_budget", "rt_render_host", "rt_resolve", "rt_resolve_host", "rt_sample_radiance", "rt_sample_radiance_sig",
                "rt_pdf_eval", "rt_ieee_div_sqrt", "rt_last_error"]
 HOST_SYMBOLS = ["rth_set_bvh_axis_seed", "rth_set_bvh_axis_mode", "rth_scene_builtin", "rth_scene_from_description", "rth_scene_free",
                 "rth_scene_describe", "rth_scene_flatten", "rth_scene_object_count", "rth_write_ppm", "rth_write_pfm", "rth_write_png",

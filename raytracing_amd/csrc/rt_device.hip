@@ -77,8 +77,58 @@ RT_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdg
 // address is taken once per device with hipGetSymbolAddress (rt_context_create) and kept in rt_context::scratch.
 #define RT_NOALLOC_MAX_RAYS (1u << 18)
 #define RT_NOALLOC_STATS_BYTES 256u
+static_assert(RT_NOALLOC_MAX_RAYS == RT_NOALLOC_MAX_RAYS_ABI, "the limit rt_abi.h documents is the size of the scratch array");
 static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_STATS_BYTES + (size_t)RT_NOALLOC_MAX_RAYS * RT_RAY_STRIDE * sizeof(double)];
 
+// Timing events of one render lane: created once, reused by every call on that lane (creating and destroying two events per
+// span cost a few microseconds each inside the timed region, and error paths leaked them), destroyed with the scene.
+struct EventPool {
+    std::vector<hipEvent_t> ev; size_t used = 0;
+    hipEvent_t get() {
+        if (used == ev.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            ev.push_back(e);
+        }
+        return ev[used++];
+    }
+    void reset() { used = 0; }
+    void destroy() { for (auto e : ev) (void)hipEventDestroy(e); ev.clear(); used = 0; }
+};
+// Events of one call that are not timing spans (pass-order events, lane joins): destroyed on every way out of the call.
+struct EventScope {
+    std::vector<hipEvent_t> ev;
+    ~EventScope() { for (auto e : ev) (void)hipEventDestroy(e); }
+    hipError_t make(hipEvent_t* out, unsigned flags) {
+        hipError_t r = hipEventCreateWithFlags(out, flags);
+        if (r == hipSuccess) ev.push_back(*out);
+        return r;
+    }
+};
+struct EventTimer {
+    struct Span { hipEvent_t a, b; int cat; };
+    std::vector<Span> spans;
+    hipStream_t s;
+    bool enabled;
+    EventPool* pool;
+    EventTimer(hipStream_t st, bool en, EventPool* p) : s(st), enabled(en && p != nullptr), pool(p) {}
+    ~EventTimer() { if (pool) pool->reset(); }   // the events go back to the pool whichever way the call ends
+    void begin(int cat) {
+        if (!enabled) return;
+        Span sp; sp.cat = cat; sp.a = pool->get(); sp.b = pool->get();
+        if (sp.a) (void)hipEventRecord(sp.a, s);
+        spans.push_back(sp);
+    }
+    void end() { if (enabled && spans.back().b) (void)hipEventRecord(spans.back().b, s); }
+    void collect(double* ms_by_cat, int ncat, uint64_t* count_by_cat) {
+        for (auto& sp : spans) {
+            float ms = 0.f;
+            if (!sp.a || !sp.b || hipEventElapsedTime(&ms, sp.a, sp.b) != hipSuccess) { (void)hipGetLastError(); continue; }
+            if (sp.cat < ncat) { ms_by_cat[sp.cat] += ms; count_by_cat[sp.cat]++; }
+        }
+        spans.clear();
+    }
+};
 struct rt_context {
     int device;
     hipStream_t stream;
@@ -87,6 +137,7 @@ struct rt_context {
     int live_scenes = 0;     // rt_scene handles that still point at this context (rt_context_destroy refuses while > 0)
 };
 
+#define RT_DEFAULT_PASS_BUDGET (80ull << 30)   /* two lanes + scene + certificate tables fit the 288 GB */
 struct Workspace {
     PathBuffers pb{};
     uint32_t* queue[2] = {nullptr, nullptr};
@@ -141,6 +192,8 @@ struct rt_scene {
     std::mutex job_mu; std::condition_variable job_cv; uint64_t jobs_recorded = 0;   // jobs whose done-event has been recorded (host side)
     std::thread worker[2];              // one host thread per lane, started by the first rt_render_begin on that lane (a fresh thread per job costs HIP's per-thread set-up every time)
     bool workers_quit = false;
+    EventPool ev_pool[2];               // timing events per lane (EventTimer)
+    uint64_t pass_budget = RT_DEFAULT_PASS_BUDGET;   // bytes of path state per lane that samples_per_pass == 0 may use (rt_scene_set_pass_budget; halved when an allocation fails)
 };
 
 struct rt_job {
@@ -195,35 +248,11 @@ static int ws_ensure(rt_scene* sc, Workspace& ws, uint32_t cap, int32_t depth) {
 
 static inline dim3 grid_for(uint32_t n) { return dim3((n + 255u) / 256u); }
 
-struct EventTimer {
-    struct Span { hipEvent_t a, b; int cat; };
-    std::vector<Span> spans;
-    hipStream_t s;
-    bool enabled;
-    explicit EventTimer(hipStream_t st, bool en) : s(st), enabled(en) {}
-    void begin(int cat) {
-        if (!enabled) return;
-        Span sp; sp.cat = cat;
-        (void)hipEventCreate(&sp.a); (void)hipEventCreate(&sp.b);
-        (void)hipEventRecord(sp.a, s);
-        spans.push_back(sp);
-    }
-    void end() { if (enabled) (void)hipEventRecord(spans.back().b, s); }
-    void collect(double* ms_by_cat, int ncat, uint64_t* count_by_cat) {
-        for (auto& sp : spans) {
-            float ms = 0.f;
-            (void)hipEventElapsedTime(&ms, sp.a, sp.b);
-            if (sp.cat < ncat) { ms_by_cat[sp.cat] += ms; count_by_cat[sp.cat]++; }
-            (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b);
-        }
-        spans.clear();
-    }
-};
 enum { CAT_TRACE = 0, CAT_SHADE = 1, CAT_OTHER = 2, CAT_SHADOW = 3, CAT_N = 4 };  // CAT_SHADOW: traversal launches of MIS shadow rays (integrator.rs:82)
 
 static void launch_trace(rt_scene* sc, unsigned long long* lstats, uint32_t lcap, hipStream_t st, bool count, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_bound, const double* rays, double t_min,
                          double t_max, uint32_t* out_prim, uint32_t* out_inst, double* out_t, uint32_t lanes = 64u, uint32_t t_stride = 1u, PathHit* out_hit = nullptr, bool shadow = false,
-                         const uint32_t* remap = nullptr, bool count_steps = true) {
+                         const uint32_t* remap = nullptr, bool count_steps = false) {
     if (n_bound == 0) return;
     SceneDev dv = sc->dev;   // this launch's copy of the kernel argument
     dv.count_steps = count_steps ? 1u : 0u;
@@ -322,7 +351,7 @@ static int capture_queue(Workspace& ws, hipStream_t st, const uint32_t* queue, u
 
 static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bool explicit_lists, uint32_t width, uint32_t height, uint32_t sample0, int32_t max_depth,
                      int32_t integrator, uint64_t seed, bool count_tests, bool sort_rays, EventTimer& tm, uint64_t& launches, uint64_t* shadow_rays = nullptr, Capture* cap = nullptr,
-                     bool lane_walk = false, bool want_sig = false, bool bins = false, bool count_steps = true) {
+                     bool lane_walk = false, bool want_sig = false, bool bins = false, bool count_steps = false) {
     PathBuffers pbk = ws.pb;   // what the kernels see: signatures only for rt_sample_radiance_sig
     if (!want_sig) pbk.sig = nullptr;
     else HIP_OK(hipMemsetAsync(pbk.sig, 0, (size_t)n * sizeof(unsigned long long), st));
@@ -930,6 +959,7 @@ int rt_scene_destroy(rt_scene* sc) {
     for (auto& w : sc->worker) if (w.joinable()) w.join();
     for (auto& e : sc->job_done) if (e) (void)hipEventDestroy(e);
     (void)hipStreamSynchronize(sc->ctx->stream);
+    for (auto& pl : sc->ev_pool) pl.destroy();
     ws_free(sc->ws); ws_free(sc->ws2);
     if (sc->stream2) (void)hipStreamDestroy(sc->stream2);
     (void)hipFree(sc->dblob);
@@ -967,6 +997,7 @@ int rt_trace_closest_device_noalloc(rt_scene* sc, uint32_t n, const double* rays
     if (!sc || (n && (!rays_dev || !prim_id_dev || !t_dev))) return fail(RT_ERR_BAD_ARG, "rt_trace_closest_device_noalloc: null argument");
     if (n > RT_NOALLOC_MAX_RAYS) return fail(RT_ERR_BAD_ARG, "rt_trace_closest_device_noalloc: more than " + std::to_string(RT_NOALLOC_MAX_RAYS) + " rays per call (the scratch array is fixed)");
     if (n == 0) return RT_OK;
+    RT_NOT_BUSY(sc, "rt_trace_closest_device_noalloc");   // it launches on the context stream, which is lane 0 of the render jobs
     HIP_OK(hipSetDevice(sc->ctx->device));
     hipStream_t st = sc->ctx->stream;
     unsigned char* base = sc->ctx->scratch;  // never the array's name: that is a host-side stand-in, not a device address
@@ -1035,11 +1066,27 @@ int rt_primary_rays(rt_scene* sc, uint32_t width, uint32_t height, uint32_t samp
     return RT_OK;
 }
 
-// samples_per_pass == 0: a pure function of the parameters (see rt_render)
-static uint32_t default_pass_size(uint32_t npix, int32_t max_depth) {
+// samples_per_pass == 0: a pure function of the parameters and the scene's pass budget (see rt_render)
+static uint32_t default_pass_size(uint32_t npix, int32_t max_depth, uint64_t budget) {
     const uint64_t by_paths = std::max<uint64_t>(1, (128ull << 20) / npix);
-    const uint64_t by_mem = std::max<uint64_t>(1, (80ull << 30) / ((uint64_t)npix * ((uint64_t)max_depth * REC_STRIDE * 8 + 320)));
+    const uint64_t by_mem = std::max<uint64_t>(1, budget / ((uint64_t)npix * ((uint64_t)max_depth * REC_STRIDE * 8 + 320)));
     return (uint32_t)std::min<uint64_t>(std::min(by_paths, by_mem), 256);
+}
+// Path buffers of one lane for a call that left the pass size to the library.  When they do not fit (a GPU that something else
+// occupies in part), the scene's budget is halved -- 80, 40, 20, 10, 5, 2.5 GiB: a fixed ladder -- and the pass size recomputed,
+// so the call renders in smaller passes instead of failing; the budget stays lowered for the scene's later calls (they cut the
+// same passes) and rt_stats.samples_per_pass reports what was used.  `halve_call`: rt_render's "at most half the call's samples".
+static int ws_ensure_default(rt_scene* sc, Workspace& ws, uint32_t npix, int32_t max_depth, uint32_t spp, bool halve_call, uint32_t& spass) {
+    for (int step = 0;; ++step) {
+        spass = default_pass_size(npix, max_depth, sc->pass_budget);
+        if (halve_call) spass = std::min(spass, (spp + 1u) / 2u);
+        spass = std::max(1u, std::min(spass, spp));
+        if ((uint64_t)npix * spass > 0x7FFFFF00ull) return fail(RT_ERR_BAD_ARG, "samples_per_pass * pixels too large");
+        int rc = ws_ensure(sc, ws, npix * spass, max_depth);
+        if (rc != RT_ERR_OOM || step >= 5 || default_pass_size(npix, max_depth, sc->pass_budget) == 1) return rc;
+        (void)hipGetLastError();
+        sc->pass_budget /= 2;
+    }
 }
 
 static int check_params(const rt_render_params* p) {
@@ -1060,6 +1107,13 @@ int rt_accum_zero(rt_context* ctx, float* accum_dev, uint32_t width, uint32_t he
     return RT_OK;
 }
 
+int rt_scene_set_pass_budget(rt_scene* sc, uint64_t bytes_per_lane) {
+    if (!sc) return fail(RT_ERR_BAD_ARG, "rt_scene_set_pass_budget: null scene");
+    RT_NOT_BUSY(sc, "rt_scene_set_pass_budget");
+    sc->pass_budget = bytes_per_lane ? bytes_per_lane : RT_DEFAULT_PASS_BUDGET;
+    return RT_OK;
+}
+
 int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stats* stats) {
     if (!sc || !accum_dev) return fail(RT_ERR_BAD_ARG, "rt_render: null argument");
     int rc = check_params(p);
@@ -1076,28 +1130,29 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
     }
     // Two passes are in flight at a time, each on its own stream with its own path buffers (a "lane"): every traversal launch
     // lasts as long as its slowest wave and the deep bounces carry few rays, so one pass alone leaves the machine part-idle
-    // for ~1/8 of its time; the other lane's kernels fill those gaps.  A pass is as large as fits in a third of the free
-    // HBM (at most 96 GiB) and 128M paths -- large passes matter for the same reason -- but not more than half the call's
-    // samples, so that both lanes have work.  The counting kernel runs on one lane (same passes, same sums).
+    // for ~1/8 of its time; the other lane's kernels fill those gaps.  The counting kernel runs on one lane (same passes, same sums).
+    // Pass size.  samples_per_pass == 0: a pure function of the parameters and the scene's pass budget (never of free memory as
+    // such or of the calls before): pass boundaries decide the order of the fp32 additions into the accumulator, so resumed,
+    // chunked and sharded renders of the same samples must cut the same passes to stay bit-identical.  Budget: 80 GiB of path
+    // state per lane (two lanes + scene fit the 288 GB; rt_scene_set_pass_budget), at most 128M paths, at most half the call's
+    // samples so that both lanes have work.  If the buffers do not fit (a shared GPU), the budget steps down its ladder
+    // (ws_ensure_default) and the call renders in smaller passes; rt_stats.samples_per_pass says which.
     uint32_t spass = p->samples_per_pass;
     if (spass == 0) {
-        // A pure function of the parameters (never of free memory or of earlier calls): pass boundaries decide the order of
-        // the fp32 additions into the accumulator, so resumed, chunked and sharded renders of the same samples must cut the
-        // same passes to stay bit-identical.  Budget: 80 GiB of path state per lane (two lanes + scene fit the 288 GB), at most
-        // 128M paths, at most half the call's samples so that both lanes have work.  If the buffers do not fit (a shared GPU),
-        // the call fails with RT_ERR_OOM and the caller chooses samples_per_pass itself.
-        spass = std::min(default_pass_size(npix, p->max_depth), (spp + 1u) / 2u);
+        rc = ws_ensure_default(sc, sc->ws, npix, p->max_depth, spp, true, spass);
+        if (rc != RT_OK) return rc;
+    } else {
+        spass = std::max(1u, std::min(spass, spp));
+        if ((uint64_t)npix * spass > 0x7FFFFF00ull) return fail(RT_ERR_BAD_ARG, "samples_per_pass * pixels too large");
+        rc = ws_ensure(sc, sc->ws, npix * spass, p->max_depth);
+        if (rc != RT_OK) return rc;
     }
-    spass = std::max(1u, std::min(spass, spp));
-    if ((uint64_t)npix * spass > 0x7FFFFF00ull) return fail(RT_ERR_BAD_ARG, "samples_per_pass * pixels too large");
     const bool count_tests = (p->flags & RT_RENDER_COUNT_TESTS) != 0;
     const bool sort_rays = (p->flags & RT_RENDER_NO_SORT) == 0 && sc->sortable;
     const uint32_t n_pass = (spp + spass - 1u) / spass;
     int n_lanes = (n_pass >= 2 && !count_tests && (p->flags & RT_RENDER_ONE_LANE) == 0) ? 2 : 1;
     hipStream_t st = sc->ctx->stream;
     if (n_lanes == 2 && !sc->stream2) HIP_OK(hipStreamCreateWithFlags(&sc->stream2, hipStreamNonBlocking));
-    rc = ws_ensure(sc, sc->ws, npix * spass, p->max_depth);
-    if (rc != RT_OK) return rc;
     if (n_lanes == 2 && (uint64_t)npix * spass >= sc->ws2_failed_cap) n_lanes = 1;      // did not fit before
     if (n_lanes == 2 && ws_ensure(sc, sc->ws2, npix * spass, p->max_depth) != RT_OK) {  // no room for a second set of path buffers:
         (void)hipGetLastError();                                                         // same passes, one after the other
@@ -1107,15 +1162,16 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
 
     struct LaneRun {
         Workspace* ws; hipStream_t st; EventTimer tm; uint64_t launches = 0, shadow_rays = 0; int rc = RT_OK; std::string err;
-        LaneRun(Workspace* w, hipStream_t s, bool timed) : ws(w), st(s), tm(s, timed) {}
+        LaneRun(Workspace* w, hipStream_t s, bool timed, EventPool* pool) : ws(w), st(s), tm(s, timed, pool) {}
     };
-    LaneRun lane[2] = {LaneRun(&sc->ws, st, stats != nullptr), LaneRun(&sc->ws2, sc->stream2, stats != nullptr)};
+    LaneRun lane[2] = {LaneRun(&sc->ws, st, stats != nullptr, &sc->ev_pool[0]), LaneRun(&sc->ws2, sc->stream2, stats != nullptr, &sc->ev_pool[1])};
     // pass k adds its sums to the accumulator after pass k-1 did (fixed order: the frame does not depend on the lanes)
+    EventScope scope;   // destroyed on every return below
     std::vector<hipEvent_t> added(n_pass, nullptr);
-    for (auto& e : added) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : added) HIP_OK(scope.make(&e, hipEventDisableTiming));
     std::mutex mu; std::condition_variable cv; uint32_t n_recorded = 0; bool broken = false;
-    hipEvent_t e0, e1, e_lane2;
-    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1)); HIP_OK(hipEventCreateWithFlags(&e_lane2, hipEventDisableTiming));
+    hipEvent_t e0 = nullptr, e1 = nullptr, e_lane2 = nullptr;
+    HIP_OK(scope.make(&e0, hipEventDefault)); HIP_OK(scope.make(&e1, hipEventDefault)); HIP_OK(scope.make(&e_lane2, hipEventDisableTiming));
     HIP_OK(hipEventRecord(e0, st));
     if (n_lanes == 2) HIP_OK(hipStreamWaitEvent(sc->stream2, e0, 0));   // work queued on the caller's stream before this call comes first
     auto run_lane = [&](int li) -> int {
@@ -1193,8 +1249,6 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
         double by_cat[CAT_N] = {0, 0, 0, 0}; uint64_t n_by_cat[CAT_N] = {0, 0, 0, 0};
         for (int li = 0; li < n_lanes; ++li) lane[li].tm.collect(by_cat, CAT_N, n_by_cat);   // releases the events
     }
-    for (auto& e : added) (void)hipEventDestroy(e);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e_lane2);
     return rc;
 }
 
@@ -1207,10 +1261,11 @@ static void job_main(rt_job* J) {
         Workspace& ws = J->lane == 0 ? sc->ws : sc->ws2;
         hipStream_t st = J->lane == 0 ? sc->ctx->stream : sc->stream2;
         const uint32_t npix = p.width * p.height, spp = p.spp_end - p.spp_begin;
-        EventTimer tm(st, true);
+        EventTimer tm(st, true, &sc->ev_pool[J->lane]);
         uint64_t launches = 0, shadow_rays = 0;
-        hipEvent_t e0, e1;
-        HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+        EventScope scope;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        HIP_OK(scope.make(&e0, hipEventDefault)); HIP_OK(scope.make(&e1, hipEventDefault));
         HIP_OK(hipEventRecord(e0, st));
         HIP_OK(hipMemsetAsync(ws.stats, 0, 16 * sizeof(unsigned long long), st));
         const bool sort_rays = (p.flags & RT_RENDER_NO_SORT) == 0 && sc->sortable;
@@ -1242,7 +1297,6 @@ static void job_main(rt_job* J) {
         HIP_OK(hipGetLastError());
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, e0, e1);
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         double by_cat[CAT_N] = {0, 0, 0, 0}; uint64_t n_by_cat[CAT_N] = {0, 0, 0, 0};
         tm.collect(by_cat, CAT_N, n_by_cat);
         rt_stats& S = J->st;
@@ -1289,12 +1343,15 @@ int rt_render_begin(rt_scene* sc, const rt_render_params* p, float* accum_dev, r
     if (sc->lane_job[lane]) return fail(RT_ERR_BAD_ARG, "rt_render_begin: two jobs are in flight already (rt_render_end the older one first)");
     HIP_OK(hipSetDevice(sc->ctx->device));
     const uint32_t npix = p->width * p->height, spp = p->spp_end - p->spp_begin;
-    uint32_t spass = p->samples_per_pass ? p->samples_per_pass : default_pass_size(npix, p->max_depth);   // one lane per job: not halved
-    spass = std::max(1u, std::min(spass, spp));
-    if ((uint64_t)npix * spass > 0x7FFFFF00ull) return fail(RT_ERR_BAD_ARG, "samples_per_pass * pixels too large");
     if (lane == 1 && !sc->stream2) HIP_OK(hipStreamCreateWithFlags(&sc->stream2, hipStreamNonBlocking));
     for (auto& e : sc->job_done) if (!e) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    rc = ws_ensure(sc, lane == 0 ? sc->ws : sc->ws2, npix * spass, p->max_depth);
+    uint32_t spass = p->samples_per_pass;
+    if (spass == 0) rc = ws_ensure_default(sc, lane == 0 ? sc->ws : sc->ws2, npix, p->max_depth, spp, false, spass);   // one lane per job: not halved
+    else {
+        spass = std::max(1u, std::min(spass, spp));
+        if ((uint64_t)npix * spass > 0x7FFFFF00ull) return fail(RT_ERR_BAD_ARG, "samples_per_pass * pixels too large");
+        rc = ws_ensure(sc, lane == 0 ? sc->ws : sc->ws2, npix * spass, p->max_depth);
+    }
     if (rc != RT_OK) return rc;
     rt_job* J = new (std::nothrow) rt_job();
     if (!J) return fail(RT_ERR_OOM, "rt_render_begin: host allocation failed");
@@ -1351,7 +1408,7 @@ int rt_capture_rays(rt_scene* sc, const rt_render_params* p, uint32_t bounce, in
     rc = ws_ensure(sc, sc->ws, npix, p->max_depth);
     if (rc != RT_OK) return rc;
     Capture cap; cap.bounce = bounce; cap.shadow = shadow != 0; cap.stride = stride; cap.max_n = max_n;
-    EventTimer tm(sc->ctx->stream, false);
+    EventTimer tm(sc->ctx->stream, false, nullptr);
     uint64_t launches = 0;
     HIP_OK(hipMemsetAsync(sc->ws.stats, 0, 16 * sizeof(unsigned long long), sc->ctx->stream));
     rc = run_paths(sc, sc->ws, sc->ctx->stream, npix, false, p->width, p->height, p->spp_begin, p->max_depth, p->integrator, p->seed, false,
@@ -1442,7 +1499,7 @@ int rt_sample_radiance_sig(rt_scene* sc, uint32_t width, uint32_t height, uint32
     hipStream_t st = sc->ctx->stream;
     HIP_OK(hipMemcpyAsync(ws.in_pixel, pixel_index, n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(ws.in_sample, sample_index, n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    EventTimer tm(st, false);
+    EventTimer tm(st, false, nullptr);
     uint64_t launches = 0;
     if (out_sig && !ws.pb.sig) { rc = ws_alloc(ws, ws.pb.sig, ws.cap); if (rc != RT_OK) { ws.pb.sig = nullptr; return rc; } }
     rc = run_paths(sc, sc->ws, sc->ctx->stream, n, true, width, height, 0, max_depth, integrator, seed, false, sc->sortable, tm, launches, nullptr, nullptr, false, out_sig != nullptr);

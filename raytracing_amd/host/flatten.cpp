@@ -361,6 +361,12 @@ struct Cursor {
 }  // namespace
 
 Scene scene_from_description(const char* text, size_t len) {
+    // the description's bvh_seed / bvh_axis_mode records hold for THIS scene only: whatever the caller had set for its own builds
+    // (rth_set_bvh_axis_seed / _mode) is back in place on every way out, so a later rth_scene_builtin builds the tree it asked for
+    struct RestoreAxes {
+        uint64_t seed = bvh_axis_seed(); uint32_t mode = bvh_axis_mode();
+        ~RestoreAxes() { bvh_axis_seed() = seed; bvh_axis_mode() = mode; }
+    } restore_axes;
     Cursor c{text, text + len};
     if (c.w() != "rtscene" || c.u() != 1) throw std::runtime_error("rtscene: bad header");
     std::vector<Arc<Texture>> tex; std::vector<Arc<Material>> mat; std::vector<Arc<Mesh>> mesh; std::vector<std::vector<std::array<uint32_t, 3>>> faces;

@@ -52,6 +52,8 @@ def test_roofline_is_a_roofline():
         assert 0 < r["traffic"] / (r["one_lane"]["avg_launch_ms"] * 1e-3) / 1e9 <= r["peak"]
         pm = r["issue_pmc"]
         assert 0 < pm["valu_issue_utilisation"] <= 1 and 0 < pm["scalar_issue_utilisation"] <= 1 and 0 < pm["measured_hbm_frac"] <= 1
+        if "measured_frac" in r:   # from r03 on: the measured-traffic fraction stands beside the modelled one, and cannot exceed it by much
+            assert r["measured_frac"] == pm["measured_hbm_frac"] and r["measured_frac"] <= 1.25 * r["one_lane"]["frac"]
     # the reference-order byte model lives under its own name and is a ratio, not a bandwidth
     assert d["algorithmic_saving"]["ratio"] > 1 and "roofline_valu" not in d
 

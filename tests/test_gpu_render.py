@@ -9,7 +9,9 @@ sides report each path's signature (a hash over the object hit and its side per 
 kind of scatter, reflect-or-refract, light picked and whether its sample counted, visible or not, the MIS .001
 gate; rt_sample_radiance_sig / orc_sample_radiance_sig).  A sample out of tolerance must have a differing
 signature (a direction moved by an ulp across a discontinuity: explained), the unexplained remainder must be
-ZERO, and differing signatures must stay rare (<= 3 % of samples).  Image level: 1e-5 relative (fp32 sums).
+ZERO, and -- so that a bug which changes a discrete decision cannot hide behind "explained" -- at most 0.5 % of the
+samples may be out of tolerance at all (the bound of round 1, before signatures existed) and at most 1 % may carry a
+differing signature.  Image level: 1e-5 relative (fp32 sums).
 """
 import numpy as np
 import pytest
@@ -29,7 +31,7 @@ def _pair(name, legacy_bvh=False, seed=5, axis="seeded"):
     return hs, orc.OracleScene(hs.describe())
 
 
-def _sample_compare(gs, osc, w, h, picks, depth, integ, seed, tol=1e-9, max_flipped=0.03):
+def _sample_compare(gs, osc, w, h, picks, depth, integ, seed, tol=1e-9, max_bad=0.005, max_flipped=0.01):
     px = np.array([p[1] * w + p[0] for p in picks], np.uint32)
     sm = np.array([p[2] for p in picks], np.uint32)
     g, gsig = gs.sample_radiance_sig(w, h, px, sm, depth, integ, seed)
@@ -41,6 +43,9 @@ def _sample_compare(gs, osc, w, h, picks, depth, integ, seed, tol=1e-9, max_flip
     same_path = gsig == osig
     unexplained = ~ok & same_path
     assert not unexplained.any(), f"{unexplained.sum()} samples took the same decisions as the oracle's path but differ by more than {tol}: {np.flatnonzero(unexplained)[:5]}"
+    # a differing signature explains a deviation but does not excuse any number of them -- a wrong discrete decision
+    # (a shadow walk that stops early on the wrong side, a wrong hit) would flip far more than an ulp at a discontinuity does
+    assert (~ok).mean() <= max_bad, f"{(~ok).mean():.4f} of the samples are out of tolerance (all with another signature than the oracle's path)"
     assert (~same_path).mean() <= max_flipped, f"{(~same_path).mean():.4f} of the paths took another branch than the oracle's"
     assert len(set(osig.tolist())) > len(picks) // 20      # the signature does tell paths apart
     return g, o
@@ -192,6 +197,42 @@ def test_pipelined_jobs_give_the_frame_of_sequential_calls(gpu_ctx, name, integ)
     del a, b2
 
 
+def test_pass_budget_sets_the_default_pass_size(gpu_ctx):
+    # samples_per_pass = 0 is a pure function of the parameters and the scene's pass budget (rt_scene_set_pass_budget)
+    hs, _ = _pair("random")
+    gs = gpu_ctx.upload(hs)
+    w, h, depth = 96, 54, 5
+    gs.set_pass_budget(3 * w * h * (depth * 96 + 320) + 10)       # room for 3 samples of every pixel per lane
+    a, sa = gs.render_host(w, h, 0, 8, depth, rt.INT_MIS, seed=4)
+    b, sb = gs.render_host(w, h, 0, 8, depth, rt.INT_MIS, seed=4, samples_per_pass=3)
+    assert sa.samples_per_pass == sb.samples_per_pass == 3 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    gs.set_pass_budget(0)                                          # back to the default (80 GiB): half the call per lane
+    c, sc_ = gs.render_host(w, h, 0, 8, depth, rt.INT_MIS, seed=4)
+    assert sc_.samples_per_pass == 4
+    gs.close()
+
+
+def test_default_pass_size_steps_down_when_the_gpu_is_occupied(gpu_ctx):
+    # with samples_per_pass = 0 (what the Rust GpuRenderer::render passes) a call must render on a part-occupied
+    # GPU instead of returning RT_ERR_OOM: the budget goes down its ladder (80 -> 40 -> ... -> 2.5 GiB), the pass size with it, and
+    # rt_stats.samples_per_pass reports it; the frame equals the one an explicit samples_per_pass of that size gives.
+    hs = rt.HostScene.builtin("simple_triangle", bvh_seed=3)
+    gs = gpu_ctx.upload(hs)
+    w, h, depth, spp = 1920, 1080, 5, 8                            # 1.66 GB of path state per sample of every pixel
+    torch.cuda.synchronize()
+    free = torch.cuda.mem_get_info()[0]
+    hog = torch.empty(free - (4 << 30), dtype=torch.uint8, device="cuda")     # leaves 4 GiB: the default pass (4 spp, 6.6 GB) cannot fit
+    try:
+        a, sa = gs.render_host(w, h, 0, spp, depth, rt.INT_MIS, seed=6)
+        assert 1 <= sa.samples_per_pass < 4 and sa.paths == w * h * spp
+        b, sb = gs.render_host(w, h, 0, spp, depth, rt.INT_MIS, seed=6, samples_per_pass=sa.samples_per_pass)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    finally:
+        gs.close()
+        del hog
+        torch.cuda.empty_cache()
+
+
 def test_converged_pagoda_mis_independent_seeds(gpu_ctx):
     # the second north-star correctness test on the scene it names: pagoda, MIS (integrator.rs:31-171), at a reduced frame the oracle
     # renders in seconds.  Stated tolerance, as below: rRMSE(gpu, oracle) <= 1.6 * rRMSE(oracle seed B, oracle seed C) + 0.01.
@@ -267,10 +308,11 @@ def test_edge_cases(gpu_ctx):
 
 # BASELINE.json configs[0..4] exactly as bench.py's WORKLOADS runs them (scene, frame, integrator, depth, the bench's default tree)
 BASELINE_CONFIGS = [("random", 400, 225, rt.INT_MIS, 50, 4), ("mesh", 1920, 1080, rt.INT_BRDF, 5, 1), ("mesh", 1920, 1080, rt.INT_MIS, 5, 1),
-                    ("simple", 1920, 1080, rt.INT_BRDF, 5, 1), ("simple_triangle", 3840, 2160, rt.INT_MIS, 5, 1)]
+                    ("simple", 1920, 1080, rt.INT_BRDF, 5, 1), ("simple_triangle", 3840, 2160, rt.INT_MIS, 5, 1),
+                    ("cornell", 3840, 2160, rt.INT_MIS, 5, 1)]      # configs[4] names both scenes: the broken cube and the instanced red/green box
 
 
-@pytest.mark.parametrize("name,w,h,integ,depth,spp", BASELINE_CONFIGS, ids=["configs0", "configs1", "configs2", "configs3", "configs4"])
+@pytest.mark.parametrize("name,w,h,integ,depth,spp", BASELINE_CONFIGS, ids=["configs0", "configs1", "configs2", "configs3", "configs4", "configs4_cornell"])
 def test_baseline_configs_at_their_full_frame_size(gpu_ctx, name, w, h, integ, depth, spp):
     # every BASELINE.json config at ITS OWN width x height and depth, on the tree the bench renders (min-area axes, seed 3):
     #  (1) 300 samples drawn over the whole frame and the first 1000 spp against the oracle's recursive integrator (1e-9 / signatures, as above);

@@ -203,6 +203,7 @@ def test_gpu_matches_committed_golden_vectors(gpu_ctx):
             ok = ((np.abs(got - ref) <= 1e-9 * (np.abs(ref) + 1e-3)) | (np.isnan(got) & np.isnan(ref))).all(axis=1)
             # a sample may leave the tolerance only if its path took another discrete decision than the frozen oracle path (signature)
             assert not (~ok & (sig == ref_sig)).any(), (name, integ, np.flatnonzero(~ok & (sig == ref_sig)))
+            assert (~ok).mean() <= 0.03, (name, integ, (~ok).mean())      # round 1's ceiling on out-of-tolerance samples, explained or not
             assert (sig != ref_sig).mean() <= 0.05, (name, integ, (sig != ref_sig).mean())
         gs.close()
 

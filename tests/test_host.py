@@ -182,6 +182,20 @@ def test_describe_round_trip():
         assert hs2.blob() == hs.blob()
 
 
+def test_a_description_does_not_change_the_callers_axis_settings():
+    # scene_from_description parses `bvh_seed` / `bvh_axis_mode` records into the process-wide build settings; they must be
+    # back on the way out, or a later rth_scene_builtin from C / Rust silently builds the other tree
+    from raytracing_amd import _ffi
+    L = _ffi.host()
+    text = rt.HostScene.builtin("random", bvh_seed=9, bvh_axis="min_area").describe()
+    assert b"bvh_axis_mode 1" in text
+    L.rth_set_bvh_axis_seed(4); L.rth_set_bvh_axis_mode(0)
+    want = rt.HostScene(L.rth_scene_builtin(b"random", rt.ASSETS.encode(), 0)).blob()          # seeded stream, seed 4
+    rt.HostScene.from_description(text)                                                          # min-area tree, seed 9
+    got = rt.HostScene(L.rth_scene_builtin(b"random", rt.ASSETS.encode(), 0)).blob()
+    assert got == want and got != rt.HostScene.from_description(text).blob()
+
+
 def test_mat4_inverse_and_sphere_transform_match_oracle():
     rng = np.random.default_rng(0)
     L = _ffi.host()

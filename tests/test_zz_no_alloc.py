@@ -36,6 +36,43 @@ def test_noalloc_entry_matches_existing_entry_twice(gpu_ctx):
         assert (p0 != rt.NONE).sum() > rays.shape[0] // 4
         assert np.array_equal(p0, p1), f"{(p0 != p1).sum()} primitive indices differ"
         assert np.array_equal(t0, t1), f"{(t0 != t1).sum()} t values differ in bits"
+    # what the entry point exists for: the call itself takes no device memory (everything it needs is in the fixed array)
+    d = torch.from_numpy(np.ascontiguousarray(small)).cuda()
+    prim = torch.zeros(small.shape[0], dtype=torch.int32, device="cuda"); t = torch.zeros(small.shape[0], dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    gs.trace_closest_device_noalloc(small.shape[0], d.data_ptr(), 0.001, 100000.0, prim.data_ptr(), t.data_ptr())
+    gpu_ctx.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0
+    gs.close()
+
+
+def test_noalloc_entry_at_its_maximum_size(gpu_ctx):
+    # n == RT_NOALLOC_MAX_RAYS fills the scratch array to its last ray block
+    hs = rt.HostScene.builtin("random", bvh_seed=3)
+    gs = gpu_ctx.upload(hs)
+    rays = gs.primary_rays(512, 512, 0, 0x5EED)
+    assert rays.shape[0] == rt.NOALLOC_MAX_RAYS
+    (p0, t0), (p1, t1) = _both(gs, gpu_ctx, rays)
+    assert np.array_equal(p0, p1) and np.array_equal(t0, t1) and (p0 != rt.NONE).sum() > rays.shape[0] // 4
+    gs.close()
+
+
+def test_noalloc_entry_waits_for_render_jobs(gpu_ctx):
+    # like its siblings it launches on the context stream (lane 0 of the render jobs): refused while jobs are in flight
+    hs = rt.HostScene.builtin("simple_triangle", bvh_seed=3)
+    gs = gpu_ctx.upload(hs)
+    w, h = 64, 36
+    acc = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+    rays = torch.zeros((8, 7), dtype=torch.float64, device="cuda"); rays[:, 5] = 1.0
+    prim = torch.zeros(8, dtype=torch.int32, device="cuda"); t = torch.zeros(8, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    job = gs.render_begin(acc.data_ptr(), w, h, 0, 2, 5, rt.INT_MIS)
+    with pytest.raises(rt.RtError, match="in flight"):
+        gs.trace_closest_device_noalloc(8, rays.data_ptr(), 0.001, 1e5, prim.data_ptr(), t.data_ptr())
+    gs.render_end(job)
+    gs.trace_closest_device_noalloc(8, rays.data_ptr(), 0.001, 1e5, prim.data_ptr(), t.data_ptr())
+    gpu_ctx.synchronize()
     gs.close()
 
 
