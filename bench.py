@@ -418,7 +418,12 @@ def report_kernels(args, R, accum, stats, jobs, rays):
     n_box, n_tri, n_sph = counted["box_tests"] / r1, counted["tri_tests"] / r1, counted["sphere_tests"] / r1
     ms_trace = sum(s["ms_trace"] for s in stats)
     ms_shadow = sum(s["ms_trace_shadow"] for s in stats)
-    launches = max(sum(s["trace_launches"] for s in stats), 1)
+    launches = sum(s["trace_launches"] for s in stats)
+    ms_tail = sum(s.get("ms_tail", 0.0) for s in stats)
+    tail_bounces = sum(s.get("tail_bounces", 0) for s in stats)
+    tail_only = launches == 0   # a frame so small that every bounce ran in the small-queue mode: its launches are timed as ONE span per pass (rt_stats.ms_tail),
+    if tail_only:               # shading included, so the traversal rate derived from it is a lower bound
+        ms_trace, launches = ms_tail, max(tail_bounces, 1)
     shadow_launches = sum(s["trace_shadow_launches"] for s in stats)
     shadow_rays = sum(s["shadow_rays"] for s in stats)
     wave_steps = stepped["trace_wave_steps"] * rays / max(stepped["rays"], 1)   # that step's record steps per ray, scaled to the timed rays (same workload and sample indices as the first timed step)
@@ -445,7 +450,8 @@ def report_kernels(args, R, accum, stats, jobs, rays):
         except Exception:
             traffic, pmc = None, {}
     return {
-        "kernel_ms": {"trace": ms_trace, "trace_shadow_part": ms_shadow, "shade": sum(s["ms_shade"] for s in stats), "other": sum(s["ms_other"] for s in stats),
+        "kernel_ms": {"trace": 0.0 if tail_only else ms_trace, "trace_shadow_part": ms_shadow, "shade": sum(s["ms_shade"] for s in stats), "other": sum(s["ms_other"] for s in stats),
+                      "tail": ms_tail, "tail_bounces": tail_bounces,   # bounces over small queues: traversal + shading + visibility launches under one span per pass
                       "total": sum(s["ms_total"] for s in stats),
                       "note": "HIP-event sums per launching stream; with two render lanes the launches of both lanes overlap, so the parts can exceed the total -- "
                               "only the one-lane figures below attribute time to a kernel"},
@@ -459,11 +465,11 @@ def report_kernels(args, R, accum, stats, jobs, rays):
                      "rays_per_launch": rays_per_launch, "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
                      "shadow": {"launches": shadow_launches, "rays": shadow_rays, "avg_launch_ms": ms_shadow / max(shadow_launches, 1)},
                      # the same launches with nothing else on the machine (untimed extra step on one lane)
-                     "one_lane": {"avg_launch_ms": alone["ms_trace"] / max(alone["trace_launches"], 1), "step_ms": alone["ms_total"],
-                                  "trace_ms": alone["ms_trace"], "trace_shadow_ms": alone["ms_trace_shadow"], "shade_ms": alone["ms_shade"],
+                     "one_lane": {"avg_launch_ms": (alone["ms_trace"] or alone.get("ms_tail", 0.0)) / max(alone["trace_launches"] or alone.get("tail_bounces", 0), 1), "step_ms": alone["ms_total"],
+                                  "trace_ms": alone["ms_trace"], "tail_ms": alone.get("ms_tail", 0.0), "trace_shadow_ms": alone["ms_trace_shadow"], "shade_ms": alone["ms_shade"],
                                   "other_ms": alone["ms_other"], "rays": alone["rays"], "shadow_rays": alone["shadow_rays"],
-                                  "achieved": bytes_per_ray * alone["rays"] / max(alone["ms_trace"], 1e-9) / 1e6,
-                                  "frac": bytes_per_ray * alone["rays"] / max(alone["ms_trace"], 1e-9) / 1e6 / HBM_PEAK_GBS},
+                                  "achieved": bytes_per_ray * alone["rays"] / max(alone["ms_trace"] + alone.get("ms_tail", 0.0), 1e-9) / 1e6,
+                                  "frac": bytes_per_ray * alone["rays"] / max(alone["ms_trace"] + alone.get("ms_tail", 0.0), 1e-9) / 1e6 / HBM_PEAK_GBS},
                      "issue_pmc": pmc,
                      "executed": {"record_steps_per_ray": wave_steps / max(rays, 1), "record_steps_per_wave": 64.0 * wave_steps / max(rays, 1)},
                      "note": "achieved = algorithmic bytes incl. cache-served re-reads: what the production kernel moves per launch (queue entry, ray block, hit record, certificate list, 136-B stream "

@@ -209,6 +209,8 @@ pub struct rt_stats {
     pub walk_tri_steps: u64,
     pub walk_slow_steps: u64,
     pub walk_iterations: u64,
+    pub ms_tail: f64,
+    pub tail_bounces: u64,
 }
 
 #[repr(C)]

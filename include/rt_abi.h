@@ -209,6 +209,10 @@ typedef struct rt_stats {
     uint64_t walk_tri_steps;         /* ... triangle-leaf visits (144 bytes each) */
     uint64_t walk_slow_steps;        /* ... visits that needed f64 arithmetic (exact box / triangle / sphere tests) */
     uint64_t walk_iterations;        /* ... block executions summed over waves (each runs ONE of fetch / record / triangle-leaf / f64 for its waiting lanes) */
+    double ms_tail;                  /* bounces over SMALL queues (fewer rays than a launch needs to outlast a host round trip; the 10-spp frame of configs[0] is
+                                      * 45 of them): traversal, shading and visibility launches timed as ONE span per pass -- per-launch events would cost
+                                      * more than the launches -- and counted in neither ms_trace / ms_shade nor trace_launches */
+    uint64_t tail_bounces;           /* bounces timed under ms_tail */
 } rt_stats;
 
 /* number of visible HIP devices (>= 0) or negative error */

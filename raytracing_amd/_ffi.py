@@ -25,7 +25,8 @@ class Stats(C.Structure):
                 ("launches", u64), ("ms_total", f64), ("ms_trace", f64), ("ms_shade", f64), ("ms_other", f64),
                 ("trace_launches", u64), ("trace_wave_steps", u64), ("filter_violations", u64),
                 ("ms_trace_shadow", f64), ("trace_shadow_launches", u64), ("shadow_rays", u64), ("samples_per_pass", u32), ("lanes", u32),
-                ("walk_run_steps", u64), ("walk_tri_steps", u64), ("walk_slow_steps", u64), ("walk_iterations", u64)]
+                ("walk_run_steps", u64), ("walk_tri_steps", u64), ("walk_slow_steps", u64), ("walk_iterations", u64),
+                ("ms_tail", f64), ("tail_bounces", u64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

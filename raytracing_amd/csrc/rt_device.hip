@@ -21,6 +21,7 @@
 #include <array>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -106,20 +107,20 @@ struct EventScope {
     }
 };
 struct EventTimer {
-    struct Span { hipEvent_t a, b; int cat; };
+    struct Span { hipEvent_t a, b; int cat; hipStream_t st; };
     std::vector<Span> spans;
     hipStream_t s;
     bool enabled;
     EventPool* pool;
     EventTimer(hipStream_t st, bool en, EventPool* p) : s(st), enabled(en && p != nullptr), pool(p) {}
     ~EventTimer() { if (pool) pool->reset(); }   // the events go back to the pool whichever way the call ends
-    void begin(int cat) {
+    void begin(int cat, hipStream_t on = nullptr) {   // `on`: the stream the span's launches go to (default: the timer's)
         if (!enabled) return;
-        Span sp; sp.cat = cat; sp.a = pool->get(); sp.b = pool->get();
-        if (sp.a) (void)hipEventRecord(sp.a, s);
+        Span sp; sp.cat = cat; sp.a = pool->get(); sp.b = pool->get(); sp.st = on ? on : s;
+        if (sp.a) (void)hipEventRecord(sp.a, sp.st);
         spans.push_back(sp);
     }
-    void end() { if (enabled && spans.back().b) (void)hipEventRecord(spans.back().b, s); }
+    void end() { if (enabled && spans.back().b) (void)hipEventRecord(spans.back().b, spans.back().st); }
     void collect(double* ms_by_cat, int ncat, uint64_t* count_by_cat) {
         for (auto& sp : spans) {
             float ms = 0.f;
@@ -137,12 +138,22 @@ struct rt_context {
     int live_scenes = 0;     // rt_scene handles that still point at this context (rt_context_destroy refuses while > 0)
 };
 
+#define RT_N_STATS 24          /* u64 counters per workspace: [0] rays, [1..3] box / triangle / sphere tests, [4..7] k_walk, [13] violations, [14] uncertified, [15] wave steps, [16] shadow rays */
+#define RT_STAT_SHADOW_RAYS 16
+#define RT_LAG 4u              /* run_paths, small queues: the host runs at most this many bounces ahead of the live counts it has seen */
+#ifndef RT_SMALL_QUEUE
+#define RT_SMALL_QUEUE (192u << 10)   /* rays: below this a traversal launch is shorter than a blocking read-back costs (see run_paths) */
+#endif
+#define RT_SMALL_QUEUE_TINY_SCENE (1u << 20)   /* the same for scenes of at most 4096 nodes */
 #define RT_DEFAULT_PASS_BUDGET (80ull << 30)   /* two lanes + scene + certificate tables fit the 288 GB */
 struct Workspace {
     PathBuffers pb{};
     uint32_t* queue[2] = {nullptr, nullptr};
     uint32_t* shadow_queue = nullptr;
-    uint32_t* counts = nullptr;  // [0],[1]: path queue counts; [2]: shadow count
+    uint32_t* counts = nullptr;  // ring, zeroed once per pass: [2b] path rays entering bounce b, [2b + 1] shadow rays of bounce b
+    hipEvent_t lag_ev[RT_LAG] = {};  // small queues: count copies in flight (run_paths)
+    hipStream_t side = nullptr;      // shadow-ray traversals run here, beside the next bounce's path-ray traversal (run_paths)
+    hipEvent_t ev_shaded = nullptr, ev_shadowed = nullptr;
     unsigned long long* stats = nullptr;  // rays, box, tri, sph
     uint32_t* in_pixel = nullptr; uint32_t* in_sample = nullptr;
     uint32_t* raw_queue = nullptr; uint32_t* raw_keys = nullptr; uint32_t* raw_squeue = nullptr; uint32_t* raw_skeys = nullptr; uint32_t* sorted_keys = nullptr;  // ray sorting
@@ -154,7 +165,7 @@ struct Workspace {
     uint4* walk_state = nullptr;    // k_walk: [RT_WALK_STATE_VEC][cap] per-ray filter state (k_walk_setup)
     uint32_t* walk_odd = nullptr;   // queue slots k_walk leaves to k_trace (rays that need the literal box test)
     uint32_t* walk_ctr = nullptr;   // [0] next queue slot to hand out, [1] entries of walk_odd
-    uint32_t* h_counts = nullptr;  // pinned host copy of counts (the live ray count of the next bounce sizes its sort and launches)
+    uint32_t* h_counts = nullptr;  // pinned host copy of the counts ring (the live ray count of the next bounce sizes its sort and launches)
     std::vector<void*> allocs;
 };
 
@@ -207,6 +218,10 @@ static bool scene_busy(rt_scene* sc) { return sc->lane_job[0] != nullptr || sc->
 static void ws_free(Workspace& ws) {
     for (void* p : ws.allocs) (void)hipFree(p);
     if (ws.h_counts) (void)hipHostFree(ws.h_counts);
+    for (auto e : ws.lag_ev) if (e) (void)hipEventDestroy(e);
+    if (ws.ev_shaded) (void)hipEventDestroy(ws.ev_shaded);
+    if (ws.ev_shadowed) (void)hipEventDestroy(ws.ev_shadowed);
+    if (ws.side) (void)hipStreamDestroy(ws.side);
     ws = Workspace();
 }
 template <class T> static int ws_alloc(Workspace& ws, T*& out, size_t count) {
@@ -229,7 +244,7 @@ static int ws_ensure(rt_scene* sc, Workspace& ws, uint32_t cap, int32_t depth) {
     WS(ws.pb.hit, cap) WS(ws.pb.info, cap)
     WS(ws.pb.terminal, 4 * (size_t)cap) WS(ws.pb.radiance, 3 * (size_t)cap)
     WS(ws.pb.records, (size_t)std::max(depth, 1) * REC_STRIDE * cap)
-    WS(ws.queue[0], cap) WS(ws.queue[1], cap) WS(ws.shadow_queue, cap) WS(ws.counts, 4) WS(ws.stats, 16)
+    WS(ws.queue[0], cap) WS(ws.queue[1], cap) WS(ws.shadow_queue, cap) WS(ws.counts, 2 * ((size_t)std::max(depth, 1) + 2)) WS(ws.stats, RT_N_STATS)
     WS(ws.in_pixel, cap) WS(ws.in_sample, cap)
     WS(ws.raw_queue, cap) WS(ws.raw_keys, cap) WS(ws.raw_squeue, cap) WS(ws.raw_skeys, cap) WS(ws.sorted_keys, cap)
     {
@@ -241,14 +256,29 @@ static int ws_ensure(rt_scene* sc, Workspace& ws, uint32_t cap, int32_t depth) {
         ws.sort_tmp = tmp; ws.sort_tmp_bytes = bytes;
     }
 #undef WS
-    if (hipHostMalloc((void**)&ws.h_counts, 4 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { ws_free(ws); return fail(RT_ERR_OOM, "pinned host allocation failed"); }
+    if (hipHostMalloc((void**)&ws.h_counts, 2 * ((size_t)std::max(depth, 1) + 2) * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { ws_free(ws); return fail(RT_ERR_OOM, "pinned host allocation failed"); }
+    for (auto& e : ws.lag_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; ws_free(ws); return fail(RT_ERR_HIP, "event creation failed"); }
+    if (hipStreamCreateWithFlags(&ws.side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ws.ev_shaded, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ws.ev_shadowed, hipEventDisableTiming) != hipSuccess) { ws_free(ws); return fail(RT_ERR_HIP, "side stream creation failed"); }
     ws.pb.cap = cap; ws.cap = cap; ws.depth = depth;
     return RT_OK;
 }
 
 static inline dim3 grid_for(uint32_t n) { return dim3((n + 255u) / 256u); }
+static int tune(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
+// Rays per wave of a traversal launch over a SMALL queue.  A wave walks the UNION of its rays' records and a launch lasts as long as its
+// slowest wave; once a queue is so small that 64 rays per wave leave most of the machine's wave slots empty, fewer rays per wave make
+// every walk shorter at no cost in throughput (large launches: 32 / 16 / 8 rays per wave measured 20-150 % slower).
+// The kernel picks the number from the queue's true count (RT_LANES_AUTO); the host, which only knows a bound, sizes the grid for the worst case.
+static uint32_t small_target_waves() { static const uint32_t v = (uint32_t)std::min(std::max(tune("RT_TUNE_SMALL_WAVES", 8192), 64), 1 << 20); return v; }
+static uint32_t small_least_lanes() { static const uint32_t v = (uint32_t)std::min(std::max(tune("RT_TUNE_MIN_LANES", 1), 1), 64); return v; }
+static uint32_t lanes_auto() { return RT_LANES_AUTO | (small_least_lanes() << 24) | small_target_waves(); }
+static uint32_t waves_auto(uint32_t bound) {   // most waves any count <= bound needs: n / 64 while 64 rays per wave are kept, else about the target
+    const uint64_t full = ((uint64_t)bound + 63u) / 64u, few = std::min<uint64_t>(((uint64_t)bound + small_least_lanes() - 1u) / small_least_lanes(), (uint64_t)small_target_waves() + 1u);
+    return (uint32_t)std::max(full, few);
+}
 
-enum { CAT_TRACE = 0, CAT_SHADE = 1, CAT_OTHER = 2, CAT_SHADOW = 3, CAT_N = 4 };  // CAT_SHADOW: traversal launches of MIS shadow rays (integrator.rs:82)
+enum { CAT_TRACE = 0, CAT_SHADE = 1, CAT_OTHER = 2, CAT_SHADOW = 3, CAT_TAIL = 4, CAT_N = 5 };  // CAT_TAIL: all launches of the small-queue bounces of a pass, one span  // CAT_SHADOW: traversal launches of MIS shadow rays (integrator.rs:82)
 
 static void launch_trace(rt_scene* sc, unsigned long long* lstats, uint32_t lcap, hipStream_t st, bool count, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_bound, const double* rays, double t_min,
                          double t_max, uint32_t* out_prim, uint32_t* out_inst, double* out_t, uint32_t lanes = 64u, uint32_t t_stride = 1u, PathHit* out_hit = nullptr, bool shadow = false,
@@ -257,7 +287,8 @@ static void launch_trace(rt_scene* sc, unsigned long long* lstats, uint32_t lcap
     SceneDev dv = sc->dev;   // this launch's copy of the kernel argument
     dv.count_steps = count_steps ? 1u : 0u;
     const uint32_t wpb = RT_TRACE_BLOCK / 64u;
-    const dim3 grid((uint32_t)((((uint64_t)n_bound + lanes - 1u) / lanes + wpb - 1u) / wpb));  // waves of `lanes` rays, RT_TRACE_BLOCK / 64 waves per block
+    const uint64_t n_waves = (lanes & RT_LANES_AUTO) ? waves_auto(n_bound) : ((uint64_t)n_bound + lanes - 1u) / lanes;
+    const dim3 grid((uint32_t)((n_waves + wpb - 1u) / wpb));  // waves of `lanes` rays, RT_TRACE_BLOCK / 64 waves per block
 #define RT_LAUNCH_TRACE_S(C, I, R, S) hipLaunchKernelGGL((k_trace<C, I, R, S>), grid, dim3(RT_TRACE_BLOCK), 0, st, dv, queue, n_ptr, n_bound, rays, lcap, t_min, t_max, out_prim, out_inst, out_t, lstats, lanes, t_stride, out_hit, remap)
 #define RT_LAUNCH_TRACE_R(C, I, R) do { if (shadow && !C) RT_LAUNCH_TRACE_S(C, I, R, !C); else RT_LAUNCH_TRACE_S(C, I, R, false); } while (0)
 #define RT_LAUNCH_TRACE(C, I) do { if (sc->reg_ray) RT_LAUNCH_TRACE_R(C, I, true); else RT_LAUNCH_TRACE_R(C, I, false); } while (0)
@@ -350,14 +381,17 @@ static int capture_queue(Workspace& ws, hipStream_t st, const uint32_t* queue, u
 }
 
 static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bool explicit_lists, uint32_t width, uint32_t height, uint32_t sample0, int32_t max_depth,
-                     int32_t integrator, uint64_t seed, bool count_tests, bool sort_rays, EventTimer& tm, uint64_t& launches, uint64_t* shadow_rays = nullptr, Capture* cap = nullptr,
-                     bool lane_walk = false, bool want_sig = false, bool bins = false, bool count_steps = false) {
+                     int32_t integrator, uint64_t seed, bool count_tests, bool sort_rays, EventTimer& tm, uint64_t& launches, Capture* cap = nullptr,
+                     bool lane_walk = false, bool want_sig = false, bool bins = false, bool count_steps = false, uint64_t* tail_bounces = nullptr) {
     PathBuffers pbk = ws.pb;   // what the kernels see: signatures only for rt_sample_radiance_sig
     if (!want_sig) pbk.sig = nullptr;
     else HIP_OK(hipMemsetAsync(pbk.sig, 0, (size_t)n * sizeof(unsigned long long), st));
     const bool use_walk = sc->walk_ok && !count_tests && lane_walk;   // opt-in (RT_RENDER_LANE_WALK): bounce >= 1 and shadow rays by the per-lane walk (k_walk)
     const uint32_t npix = width * height;
+    if (max_depth > ws.depth && max_depth > 1) return fail(RT_ERR_BAD_ARG, "run_paths: workspace sized for a smaller depth");
     tm.begin(CAT_OTHER);
+    // the counts ring starts at zero: k_shade of bounce b adds to [2b + 1] (shadow rays) and [2b + 2] (rays of bounce b + 1)
+    HIP_OK(hipMemsetAsync(ws.counts, 0, 2 * ((size_t)max_depth + 1) * sizeof(uint32_t), st));
     hipLaunchKernelGGL(k_raygen, grid_for(n), dim3(256), 0, st, sc->dev.camera, width, height, n, sample0, npix,
                        explicit_lists ? ws.in_pixel : nullptr, explicit_lists ? ws.in_sample : nullptr, seed, ws.pb.rays, ws.cap, ws.pb.info,
                        explicit_lists ? 0u : 1u);
@@ -366,20 +400,50 @@ static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bo
     tm.end();
     launches += 3;
     int cur = 0;
-    uint32_t live = n;  // rays in queue[cur]: read back after every shade (one 8-byte copy and a stream sync per bounce), so
-                        // that sorts and launches of the thin deeper bounces are sized to the survivors, not to the pass
+    // `live`: rays in queue[cur], or an upper bound of them.
+    //  * Large queues: read back after every shade (one 8-byte copy and a stream sync per bounce), so that the sorts and launches of the
+    //    next bounce are sized to the survivors, not to the pass.
+    //  * Small queues (<= RT_SMALL_QUEUE rays: a traversal launch over them is shorter than that round trip costs -- the 10-spp frame
+    //    of configs[0] is 50 bounces of a few thousand rays): no blocking read-back and no sort.  Every kernel takes its count from the
+    //    device (n_ptr) and is launched over the bound; the counts are copied to the host asynchronously and the host stays at most RT_LAG
+    //    bounces ahead of the newest count it has seen, which (counts only shrink) tightens the bound and ends the loop once a queue
+    //    is empty.  A path's radiance does not depend on where in a queue it sits, so the frame is the same bit for bit.
+    uint32_t live = n;
+    int32_t lag_from = -1;   // first bounce run in the small-queue mode
+    const bool may_lag = cap == nullptr && !use_walk && !(sc->bin_materials && bins);
+    // Shadow rays (integrator.rs:82) are needed by k_unwind only: their traversal runs on the workspace's side stream, beside the next
+    // bounce's path-ray traversal.  The next k_shade rewrites the per-path shadow-ray blocks, so it waits for that traversal.
+    static const bool side_on = tune("RT_TUNE_SHADOW_SIDE", 1) != 0;
+    // "small" = a traversal launch over the queue is shorter than the sort and the host round trip that would size it: scenes of a few hundred
+    // nodes walk a few dozen records per ray (random spheres: 900 k unsorted rays in 0.15-0.4 ms against 0.4 ms for the two sorts alone)
+    static const int small_tuned = tune("RT_TUNE_SMALL_QUEUE", 0);
+    const uint32_t small_queue = small_tuned > 0 ? (uint32_t)small_tuned : sc->hdr.n_nodes <= 4096u ? RT_SMALL_QUEUE_TINY_SCENE : RT_SMALL_QUEUE;
+    const bool side = side_on && cap == nullptr && !use_walk && !count_tests;
+    bool shadow_pending = false;
     for (int32_t bounce = 0; bounce < max_depth && live > 0; ++bounce) {
         const int nxt = cur ^ 1;
-        HIP_OK(hipMemsetAsync(ws.counts + nxt, 0, sizeof(uint32_t), st));
-        HIP_OK(hipMemsetAsync(ws.counts + 2, 0, sizeof(uint32_t), st));
-        tm.begin(CAT_TRACE);
-        if (use_walk && bounce >= 1) { int rc = launch_walk(sc, ws, st, ws.queue[cur], ws.counts + cur, live, ws.pb.rays, 0.001, 100000.0, ws.pb.hit, nullptr, 1u, false); if (rc != RT_OK) return rc; }
-        else launch_trace(sc, ws.stats, ws.cap, st, count_tests, ws.queue[cur], ws.counts + cur, live, ws.pb.rays, 0.001, 100000.0, nullptr, nullptr, nullptr, 64u, 1u, ws.pb.hit, false, nullptr, count_steps);  // integrator.rs:38
-        tm.end();
+        uint32_t* c_in = ws.counts + 2 * (size_t)bounce;
+        uint32_t* c_shadow = c_in + 1;
+        uint32_t* c_next = c_in + 2;
+        const bool small = may_lag && live <= small_queue;
+        if (small && lag_from < 0) { lag_from = bounce; tm.begin(CAT_TAIL); }   // from here on ONE span: an event pair per launch would cost more than the launches
+        // every RT_LAG-th small bounce leaves its counts on the host; RT_LAG bounces later they have arrived (or are about to)
+        if (small && bounce - lag_from >= (int32_t)RT_LAG && (bounce - lag_from) % (int32_t)RT_LAG == 0) {
+            const int32_t j = bounce - (int32_t)RT_LAG;
+            HIP_OK(hipEventSynchronize(ws.lag_ev[0]));
+            live = std::min(live, ws.h_counts[2 * (size_t)j + 2]);   // rays that entered bounce j + 1 >= rays entering this one
+            if (live == 0) break;
+        }
+        if (small && tail_bounces) *tail_bounces += 1;
+        if (!small) tm.begin(CAT_TRACE);
+        if (use_walk && bounce >= 1) { int rc = launch_walk(sc, ws, st, ws.queue[cur], c_in, live, ws.pb.rays, 0.001, 100000.0, ws.pb.hit, nullptr, 1u, false); if (rc != RT_OK) return rc; }
+        else launch_trace(sc, ws.stats, ws.cap, st, count_tests, ws.queue[cur], c_in, live, ws.pb.rays, 0.001, 100000.0, nullptr, nullptr, nullptr, small ? lanes_auto() : 64u, 1u, ws.pb.hit, false, nullptr, count_steps);  // integrator.rs:38
+        if (!small) tm.end();
         if (cap && !cap->shadow && (uint32_t)bounce == cap->bounce) return capture_queue(ws, st, ws.queue[cur], live, ws.pb.rays, ws.pb.hit, nullptr, *cap);
         const bool mis_shadow = integrator == RT_INT_MIS && sc->dev.n_lights > 0;
         const bool last_bounce = bounce + 1 >= max_depth;
-        tm.begin(CAT_SHADE);
+        if (shadow_pending) { HIP_OK(hipStreamWaitEvent(st, ws.ev_shadowed, 0)); shadow_pending = false; }   // k_shade rewrites the shadow-ray blocks
+        if (!small) tm.begin(CAT_SHADE);
         const uint32_t* order = nullptr;
         if (sc->bin_materials && bins) {   // opt-in (RT_RENDER_MATERIAL_BINS): regroup the queue's slots by the material class of their hits (compaction by material)
             if (!ws.order) {   // first use on this workspace (freed with it)
@@ -395,43 +459,59 @@ static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bo
             order = ws.order;
             launches += 3;
         }
-        // shade appends survivors (and, when sorting, their coherence keys) compactly to the raw queues
-        if (sort_rays)
-            hipLaunchKernelGGL(k_shade, dim3((live + RT_SHADE_BLOCK * RT_SHADE_TILES - 1u) / (RT_SHADE_BLOCK * RT_SHADE_TILES)), dim3(RT_SHADE_BLOCK), 0, st, sc->dev, pbk, ws.queue[cur], order, ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
-                               seed, ws.raw_queue, ws.raw_keys, ws.counts + nxt, ws.raw_squeue, ws.raw_skeys, ws.counts + 2);
+        // shade appends survivors compactly: to the raw queues with their coherence keys when the next bounce is sorted, else straight to the next queues
+        const bool sorted = sort_rays && !small;
+        const dim3 sgrid((live + RT_SHADE_BLOCK * RT_SHADE_TILES - 1u) / (RT_SHADE_BLOCK * RT_SHADE_TILES));
+        if (sorted)
+            hipLaunchKernelGGL(k_shade, sgrid, dim3(RT_SHADE_BLOCK), 0, st, sc->dev, pbk, ws.queue[cur], order, c_in, (uint32_t)bounce, max_depth, integrator,
+                               seed, ws.raw_queue, ws.raw_keys, c_next, ws.raw_squeue, ws.raw_skeys, c_shadow);
         else
-            hipLaunchKernelGGL(k_shade_dense, dim3((live + RT_SHADE_BLOCK * RT_SHADE_TILES - 1u) / (RT_SHADE_BLOCK * RT_SHADE_TILES)), dim3(RT_SHADE_BLOCK), 0, st, sc->dev, pbk, ws.queue[cur], order, ws.counts + cur, (uint32_t)bounce, max_depth, integrator,
-                               seed, ws.queue[nxt], (uint32_t*)nullptr, ws.counts + nxt, ws.shadow_queue, (uint32_t*)nullptr, ws.counts + 2);
-        HIP_OK(hipMemcpyAsync(ws.h_counts, ws.counts, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        HIP_OK(hipStreamSynchronize(st));
-        const uint32_t next_live = std::min(ws.h_counts[nxt], n), shadow_live = std::min(ws.h_counts[2], n);
-        if (sort_rays) {  // the sorted order lands in queue[nxt] / shadow_queue
-            int rc = RT_OK;
-            if (mis_shadow && shadow_live) rc = sort_queue(ws, st, shadow_live, ws.raw_skeys, ws.raw_squeue, ws.shadow_queue);
-            if (rc == RT_OK && !last_bounce && next_live) rc = sort_queue(ws, st, next_live, ws.raw_keys, ws.raw_queue, ws.queue[nxt]);
-            if (rc != RT_OK) return rc;
+            hipLaunchKernelGGL(k_shade_dense, sgrid, dim3(RT_SHADE_BLOCK), 0, st, sc->dev, pbk, ws.queue[cur], order, c_in, (uint32_t)bounce, max_depth, integrator,
+                               seed, ws.queue[nxt], (uint32_t*)nullptr, c_next, ws.shadow_queue, (uint32_t*)nullptr, c_shadow);
+        uint32_t next_live = live, shadow_live = live;   // small queues: bounds
+        if (small) {
+            if ((bounce - lag_from) % (int32_t)RT_LAG == 0) {
+                HIP_OK(hipMemcpyAsync(ws.h_counts + 2 * (size_t)bounce + 1, c_shadow, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                HIP_OK(hipEventRecord(ws.lag_ev[0], st));
+            }
+        } else {
+            HIP_OK(hipMemcpyAsync(ws.h_counts + 2 * (size_t)bounce + 1, c_shadow, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIP_OK(hipStreamSynchronize(st));
+            next_live = std::min(ws.h_counts[2 * (size_t)bounce + 2], n); shadow_live = std::min(ws.h_counts[2 * (size_t)bounce + 1], n);
         }
-        tm.end();
+        const bool do_shadow = mis_shadow && shadow_live;
+        if (sorted && do_shadow) { int rc = sort_queue(ws, st, shadow_live, ws.raw_skeys, ws.raw_squeue, ws.shadow_queue); if (rc != RT_OK) return rc; }   // the sorted order lands in shadow_queue
+        hipStream_t sst = st;
+        if (do_shadow && side) {   // everything the shadow traversal reads is in place on the main stream here
+            HIP_OK(hipEventRecord(ws.ev_shaded, st));
+            HIP_OK(hipStreamWaitEvent(ws.side, ws.ev_shaded, 0));
+            sst = ws.side;
+        }
+        if (sorted && !last_bounce && next_live) { int rc = sort_queue(ws, st, next_live, ws.raw_keys, ws.raw_queue, ws.queue[nxt]); if (rc != RT_OK) return rc; }
+        if (!small) tm.end();
         launches += 2;
-        if (mis_shadow && shadow_live) {
-            if (shadow_rays) *shadow_rays += shadow_live;
-            tm.begin(CAT_SHADOW);
+        if (do_shadow) {
+            if (!small) tm.begin(CAT_SHADOW, sst);
             double* t_shadow = ws.pb.records + (size_t)bounce * ws.cap * REC_STRIDE + REC_T_SHADOW;
-            if (use_walk) { int rc = launch_walk(sc, ws, st, ws.shadow_queue, ws.counts + 2, shadow_live, ws.pb.shadow_rays, 0.001, 10000.0, nullptr, t_shadow, (uint32_t)REC_STRIDE, true); if (rc != RT_OK) return rc; }
-            else launch_trace(sc, ws.stats, ws.cap, st, count_tests, ws.shadow_queue, ws.counts + 2, shadow_live, ws.pb.shadow_rays, 0.001, 10000.0, nullptr, nullptr,
-                              t_shadow, 64u, (uint32_t)REC_STRIDE, nullptr, true, nullptr, count_steps);  // integrator.rs:82
-            tm.end();
+            if (use_walk) { int rc = launch_walk(sc, ws, st, ws.shadow_queue, c_shadow, shadow_live, ws.pb.shadow_rays, 0.001, 10000.0, nullptr, t_shadow, (uint32_t)REC_STRIDE, true); if (rc != RT_OK) return rc; }
+            else launch_trace(sc, ws.stats, ws.cap, sst, count_tests, ws.shadow_queue, c_shadow, shadow_live, ws.pb.shadow_rays, 0.001, 10000.0, nullptr, nullptr,
+                              t_shadow, small ? lanes_auto() : 64u, (uint32_t)REC_STRIDE, nullptr, true, nullptr, count_steps);  // integrator.rs:82
+            if (!small) tm.end();
             launches += 1;
+            if (sst != st) { HIP_OK(hipEventRecord(ws.ev_shadowed, sst)); shadow_pending = true; }
             if (cap && cap->shadow && (uint32_t)bounce == cap->bounce)
                 return capture_queue(ws, st, ws.shadow_queue, shadow_live, ws.pb.shadow_rays, nullptr, ws.pb.records + (size_t)bounce * ws.cap * REC_STRIDE + REC_T_SHADOW, *cap);
         }
         cur = nxt;
         live = next_live;
     }
+    if (shadow_pending) HIP_OK(hipStreamWaitEvent(st, ws.ev_shadowed, 0));   // k_unwind reads the visibility results
+    if (lag_from >= 0) tm.end();   // CAT_TAIL (the visibility launches on the side stream have been waited for)
     tm.begin(CAT_OTHER);
     hipLaunchKernelGGL(k_unwind, grid_for(n), dim3(256), 0, st, pbk, n);
+    hipLaunchKernelGGL(k_sum_shadow_counts, dim3(1), dim3(64), 0, st, ws.counts, (uint32_t)max_depth, ws.stats + RT_STAT_SHADOW_RAYS);   // rt_stats.shadow_rays, whichever mode the bounces ran in
     tm.end();
-    launches += 1;
+    launches += 2;
     HIP_OK(hipGetLastError());
     return RT_OK;
 }
@@ -1003,7 +1083,7 @@ int rt_trace_closest_device_noalloc(rt_scene* sc, uint32_t n, const double* rays
     unsigned char* base = sc->ctx->scratch;  // never the array's name: that is a host-side stand-in, not a device address
     unsigned long long* stats = (unsigned long long*)base;
     double* staged = (double*)(base + RT_NOALLOC_STATS_BYTES);
-    HIP_OK(hipMemsetAsync(stats, 0, 16 * sizeof(unsigned long long), st));  // the array keeps the last call's contents; the ray blocks are rewritten below
+    HIP_OK(hipMemsetAsync(stats, 0, RT_N_STATS * sizeof(unsigned long long), st));  // the array keeps the last call's contents; the ray blocks are rewritten below
     hipLaunchKernelGGL(k_aos_to_soa, grid_for(n), dim3(256), 0, st, rays_dev, n, staged, RT_NOALLOC_MAX_RAYS);
     launch_trace(sc, stats, RT_NOALLOC_MAX_RAYS, st, false, nullptr, nullptr, n, staged, t_min, t_max, prim_id_dev, nullptr, t_dev);
     HIP_OK(hipGetLastError());
@@ -1024,11 +1104,11 @@ int rt_trace_closest(rt_scene* sc, uint32_t n, const double* rays, double t_min,
     for (uint32_t i = 0; i < n; ++i)
         for (int c = 0; c < 7; ++c) soa[(size_t)i * RT_RAY_STRIDE + c] = rays[(size_t)i * 7 + c];
     HIP_OK(hipMemcpyAsync(ws.pb.rays, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemsetAsync(ws.stats, 0, 16 * sizeof(unsigned long long), st));
+    HIP_OK(hipMemsetAsync(ws.stats, 0, RT_N_STATS * sizeof(unsigned long long), st));
     launch_trace(sc, counters != nullptr, nullptr, nullptr, n, ws.pb.rays, t_min, t_max, ws.pb.hit_prim, ws.pb.hit_inst, ws.pb.hit_t);
     HIP_OK(hipGetLastError());
     std::vector<uint32_t> hp(n), hi(n);
-    unsigned long long st4[16];
+    unsigned long long st4[RT_N_STATS];
     HIP_OK(hipMemcpyAsync(hp.data(), ws.pb.hit_prim, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(hi.data(), ws.pb.hit_inst, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(t, ws.pb.hit_t, n * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1161,7 +1241,7 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
     }
 
     struct LaneRun {
-        Workspace* ws; hipStream_t st; EventTimer tm; uint64_t launches = 0, shadow_rays = 0; int rc = RT_OK; std::string err;
+        Workspace* ws; hipStream_t st; EventTimer tm; uint64_t launches = 0, tail_bounces = 0; int rc = RT_OK; std::string err;
         LaneRun(Workspace* w, hipStream_t s, bool timed, EventPool* pool) : ws(w), st(s), tm(s, timed, pool) {}
     };
     LaneRun lane[2] = {LaneRun(&sc->ws, st, stats != nullptr, &sc->ev_pool[0]), LaneRun(&sc->ws2, sc->stream2, stats != nullptr, &sc->ev_pool[1])};
@@ -1178,12 +1258,12 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
         LaneRun& L = lane[li];
         Workspace& ws = *L.ws;
         HIP_OK(hipSetDevice(sc->ctx->device));
-        HIP_OK(hipMemsetAsync(ws.stats, 0, 16 * sizeof(unsigned long long), L.st));
+        HIP_OK(hipMemsetAsync(ws.stats, 0, RT_N_STATS * sizeof(unsigned long long), L.st));
         for (uint32_t k = (uint32_t)li; k < n_pass; k += (uint32_t)n_lanes) {
             const uint32_t s0 = p->spp_begin + k * spass;
             const uint32_t ns = std::min(spass, p->spp_end - s0);
-            int r = run_paths(sc, ws, L.st, npix * ns, false, p->width, p->height, s0, p->max_depth, p->integrator, p->seed, count_tests, sort_rays, L.tm, L.launches, &L.shadow_rays, nullptr, (p->flags & RT_RENDER_LANE_WALK) != 0, false,
-                              (p->flags & RT_RENDER_MATERIAL_BINS) != 0, (p->flags & (RT_RENDER_COUNT_STEPS | RT_RENDER_COUNT_TESTS)) != 0);
+            int r = run_paths(sc, ws, L.st, npix * ns, false, p->width, p->height, s0, p->max_depth, p->integrator, p->seed, count_tests, sort_rays, L.tm, L.launches, nullptr, (p->flags & RT_RENDER_LANE_WALK) != 0, false,
+                              (p->flags & RT_RENDER_MATERIAL_BINS) != 0, (p->flags & (RT_RENDER_COUNT_STEPS | RT_RENDER_COUNT_TESTS)) != 0, &L.tail_bounces);
             if (r != RT_OK) return r;
             if (k > 0) {
                 std::unique_lock<std::mutex> lk(mu);
@@ -1216,7 +1296,7 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
         guarded(0);
         if (t2.joinable()) t2.join();
     } else guarded(0);
-    unsigned long long st4[16] = {}, st4b[16] = {};
+    unsigned long long st4[RT_N_STATS] = {}, st4b[RT_N_STATS] = {};
     hipError_t he = hipSuccess;
     if (n_lanes == 2) {
         he = hipEventRecord(e_lane2, sc->stream2);
@@ -1235,18 +1315,18 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
     if (stats && rc == RT_OK) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, e0, e1);
-        double by_cat[CAT_N] = {0, 0, 0, 0}; uint64_t n_by_cat[CAT_N] = {0, 0, 0, 0};
+        double by_cat[CAT_N] = {}; uint64_t n_by_cat[CAT_N] = {};
         for (int li = 0; li < n_lanes; ++li) lane[li].tm.collect(by_cat, CAT_N, n_by_cat);
-        for (int k = 0; k < 16; ++k) st4[k] += st4b[k];
+        for (int k = 0; k < RT_N_STATS; ++k) st4[k] += st4b[k];
         stats->rays = st4[0]; stats->box_tests = st4[1]; stats->tri_tests = st4[2]; stats->sphere_tests = st4[3];
         stats->paths = (uint64_t)npix * spp; stats->launches = lane[0].launches + lane[1].launches;
         stats->ms_total = ms; stats->ms_trace = by_cat[CAT_TRACE] + by_cat[CAT_SHADOW]; stats->ms_shade = by_cat[CAT_SHADE]; stats->ms_other = by_cat[CAT_OTHER];
         stats->trace_launches = n_by_cat[CAT_TRACE] + n_by_cat[CAT_SHADOW]; stats->filter_violations = st4[13]; stats->trace_wave_steps = st4[15];
         stats->ms_trace_shadow = by_cat[CAT_SHADOW]; stats->trace_shadow_launches = n_by_cat[CAT_SHADOW];
-        stats->shadow_rays = lane[0].shadow_rays + lane[1].shadow_rays; stats->samples_per_pass = spass; stats->lanes = (uint32_t)n_lanes;
+        stats->shadow_rays = st4[RT_STAT_SHADOW_RAYS]; stats->ms_tail = by_cat[CAT_TAIL]; stats->tail_bounces = lane[0].tail_bounces + lane[1].tail_bounces; stats->samples_per_pass = spass; stats->lanes = (uint32_t)n_lanes;
         stats->walk_run_steps = st4[4]; stats->walk_tri_steps = st4[5]; stats->walk_slow_steps = st4[6]; stats->walk_iterations = st4[7];
     } else {
-        double by_cat[CAT_N] = {0, 0, 0, 0}; uint64_t n_by_cat[CAT_N] = {0, 0, 0, 0};
+        double by_cat[CAT_N] = {}; uint64_t n_by_cat[CAT_N] = {};
         for (int li = 0; li < n_lanes; ++li) lane[li].tm.collect(by_cat, CAT_N, n_by_cat);   // releases the events
     }
     return rc;
@@ -1262,18 +1342,18 @@ static void job_main(rt_job* J) {
         hipStream_t st = J->lane == 0 ? sc->ctx->stream : sc->stream2;
         const uint32_t npix = p.width * p.height, spp = p.spp_end - p.spp_begin;
         EventTimer tm(st, true, &sc->ev_pool[J->lane]);
-        uint64_t launches = 0, shadow_rays = 0;
+        uint64_t launches = 0, tail_bounces = 0;
         EventScope scope;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         HIP_OK(scope.make(&e0, hipEventDefault)); HIP_OK(scope.make(&e1, hipEventDefault));
         HIP_OK(hipEventRecord(e0, st));
-        HIP_OK(hipMemsetAsync(ws.stats, 0, 16 * sizeof(unsigned long long), st));
+        HIP_OK(hipMemsetAsync(ws.stats, 0, RT_N_STATS * sizeof(unsigned long long), st));
         const bool sort_rays = (p.flags & RT_RENDER_NO_SORT) == 0 && sc->sortable;
         bool waited = J->seq == 0;
         for (uint32_t s0 = p.spp_begin; s0 < p.spp_end; s0 += J->spass) {
             const uint32_t ns = std::min(J->spass, p.spp_end - s0);
-            int r = run_paths(sc, ws, st, npix * ns, false, p.width, p.height, s0, p.max_depth, p.integrator, p.seed, false, sort_rays, tm, launches, &shadow_rays, nullptr,
-                              (p.flags & RT_RENDER_LANE_WALK) != 0, false, (p.flags & RT_RENDER_MATERIAL_BINS) != 0, (p.flags & (RT_RENDER_COUNT_STEPS | RT_RENDER_COUNT_TESTS)) != 0);
+            int r = run_paths(sc, ws, st, npix * ns, false, p.width, p.height, s0, p.max_depth, p.integrator, p.seed, false, sort_rays, tm, launches, nullptr,
+                              (p.flags & RT_RENDER_LANE_WALK) != 0, false, (p.flags & RT_RENDER_MATERIAL_BINS) != 0, (p.flags & (RT_RENDER_COUNT_STEPS | RT_RENDER_COUNT_TESTS)) != 0, &tail_bounces);
             if (r != RT_OK) return r;
             if (!waited) {   // the job begun before this one adds its sums first (fixed order of the fp32 additions)
                 std::unique_lock<std::mutex> lk(sc->job_mu);
@@ -1291,19 +1371,19 @@ static void job_main(rt_job* J) {
         { std::lock_guard<std::mutex> lk(sc->job_mu); sc->jobs_recorded = J->seq + 1; }
         sc->job_cv.notify_all();
         HIP_OK(hipEventRecord(e1, st));
-        unsigned long long st4[16] = {};
+        unsigned long long st4[RT_N_STATS] = {};
         HIP_OK(hipMemcpyAsync(st4, ws.stats, sizeof st4, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
         HIP_OK(hipGetLastError());
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, e0, e1);
-        double by_cat[CAT_N] = {0, 0, 0, 0}; uint64_t n_by_cat[CAT_N] = {0, 0, 0, 0};
+        double by_cat[CAT_N] = {}; uint64_t n_by_cat[CAT_N] = {};
         tm.collect(by_cat, CAT_N, n_by_cat);
         rt_stats& S = J->st;
         S.rays = st4[0]; S.paths = (uint64_t)npix * spp; S.launches = launches; S.ms_total = ms;
         S.ms_trace = by_cat[CAT_TRACE] + by_cat[CAT_SHADOW]; S.ms_shade = by_cat[CAT_SHADE]; S.ms_other = by_cat[CAT_OTHER];
         S.trace_launches = n_by_cat[CAT_TRACE] + n_by_cat[CAT_SHADOW]; S.trace_wave_steps = st4[15];
-        S.ms_trace_shadow = by_cat[CAT_SHADOW]; S.trace_shadow_launches = n_by_cat[CAT_SHADOW]; S.shadow_rays = shadow_rays;
+        S.ms_trace_shadow = by_cat[CAT_SHADOW]; S.trace_shadow_launches = n_by_cat[CAT_SHADOW]; S.shadow_rays = st4[RT_STAT_SHADOW_RAYS]; S.ms_tail = by_cat[CAT_TAIL]; S.tail_bounces = tail_bounces;
         S.samples_per_pass = J->spass; S.lanes = 1;
         S.walk_run_steps = st4[4]; S.walk_tri_steps = st4[5]; S.walk_slow_steps = st4[6]; S.walk_iterations = st4[7];
         return RT_OK;
@@ -1410,9 +1490,9 @@ int rt_capture_rays(rt_scene* sc, const rt_render_params* p, uint32_t bounce, in
     Capture cap; cap.bounce = bounce; cap.shadow = shadow != 0; cap.stride = stride; cap.max_n = max_n;
     EventTimer tm(sc->ctx->stream, false, nullptr);
     uint64_t launches = 0;
-    HIP_OK(hipMemsetAsync(sc->ws.stats, 0, 16 * sizeof(unsigned long long), sc->ctx->stream));
+    HIP_OK(hipMemsetAsync(sc->ws.stats, 0, RT_N_STATS * sizeof(unsigned long long), sc->ctx->stream));
     rc = run_paths(sc, sc->ws, sc->ctx->stream, npix, false, p->width, p->height, p->spp_begin, p->max_depth, p->integrator, p->seed, false,
-                   (p->flags & RT_RENDER_NO_SORT) == 0 && sc->sortable, tm, launches, nullptr, &cap, (p->flags & RT_RENDER_LANE_WALK) != 0);
+                   (p->flags & RT_RENDER_NO_SORT) == 0 && sc->sortable, tm, launches, &cap, (p->flags & RT_RENDER_LANE_WALK) != 0);
     HIP_OK(hipStreamSynchronize(sc->ctx->stream));
     if (rc != RT_OK) return rc;
     const uint32_t n = (uint32_t)cap.prim.size();
@@ -1502,7 +1582,7 @@ int rt_sample_radiance_sig(rt_scene* sc, uint32_t width, uint32_t height, uint32
     EventTimer tm(st, false, nullptr);
     uint64_t launches = 0;
     if (out_sig && !ws.pb.sig) { rc = ws_alloc(ws, ws.pb.sig, ws.cap); if (rc != RT_OK) { ws.pb.sig = nullptr; return rc; } }
-    rc = run_paths(sc, sc->ws, sc->ctx->stream, n, true, width, height, 0, max_depth, integrator, seed, false, sc->sortable, tm, launches, nullptr, nullptr, false, out_sig != nullptr);
+    rc = run_paths(sc, sc->ws, sc->ctx->stream, n, true, width, height, 0, max_depth, integrator, seed, false, sc->sortable, tm, launches, nullptr, false, out_sig != nullptr);
     if (rc != RT_OK) return rc;
     if (out_sig) HIP_OK(hipMemcpyAsync(out_sig, ws.pb.sig, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     std::vector<double> rad(3 * (size_t)ws.cap);

@@ -499,6 +499,13 @@ __global__ void k_iota(uint32_t* q, uint32_t n) {
     if (i < n) q[i] = i;
 }
 __global__ void k_set_u32(uint32_t* p, uint32_t v) { *p = v; }
+// run_paths' counts ring: [2b + 1] = shadow rays of bounce b.  One wave adds their sum to a statistics slot (rt_stats.shadow_rays).
+__global__ __launch_bounds__(64) void k_sum_shadow_counts(const uint32_t* __restrict__ counts, uint32_t depth, unsigned long long* __restrict__ out) {
+    uint64_t s = 0;
+    for (uint32_t b = threadIdx.x; b < depth; b += 64u) s += counts[2u * b + 1u];
+    s = wave_sum_u64(s);
+    if (threadIdx.x == 0 && s) atomicAdd(out, (unsigned long long)s);
+}
 // rt_pdf_eval: PDF::value / PDF::generate of pdf.rs for n independent items, each a list of n_comp PDFs (n_comp > 1: MixturePDF Uniform)
 #define RT_PDF_MAX_COMP 8u
 __global__ __launch_bounds__(256) void k_pdf_eval(uint32_t n, uint32_t n_comp, const rt_pdf_desc* __restrict__ descs, const double* __restrict__ dirs, uint64_t seed,

@@ -864,6 +864,7 @@ RT_DEV void traverse(const SceneDev& sc, uint32_t first, const RAYSRC& src, HIT&
     }
 }
 
+#define RT_LANES_AUTO 0x80000000u   /* k_trace's `lanes` argument: bit 31 | least lanes (7 bits) << 24 | target waves (24 bits) */
 #ifndef RT_TRACE_BLOCK
 #define RT_TRACE_BLOCK 64    /* threads per k_trace block: ONE wave.  A block keeps its LDS until its last wave ends, and the walks are long-tailed (mean 260 steps,
                                 * max 5 600): with four waves per block the finished waves' LDS stayed allocated and kept new blocks out.  256 / 128 / 64: 1 960 / 2 018 / 2 090 Mrays/s (r02k) */
@@ -890,6 +891,12 @@ __global__ __launch_bounds__(RT_TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(
     // `lanes` rays per wave (64, or fewer for incoherent queues: the wave walks the UNION of its rays' visited records)
     // remap (k_walk's left-overs): the launch covers the n queue SLOTS listed in remap instead of slots 0..n-1
     const uint32_t n = n_ptr ? *n_ptr : n_fixed;
+    if (lanes & RT_LANES_AUTO) {   // small queues: rays per wave from the TRUE count (the host only knows a bound): the largest power of two <= 64 that still
+        const uint32_t target = lanes & 0xFFFFFFu, least = (lanes >> 24) & 0x7Fu;   // leaves about `target` waves, at least `least`
+        uint32_t l = 64u;
+        while (l > least && n <= target * (l >> 1)) l >>= 1;
+        lanes = l;
+    }
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t wave_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)((tid >> 6) * lanes));
     if (tid == 0 && stats && !remap) atomicAdd(&stats[0], (unsigned long long)n);  // rays traced (remapped rays were counted by k_walk_setup)
