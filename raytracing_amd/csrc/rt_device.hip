@@ -1161,6 +1161,7 @@ static int ws_ensure_default(rt_scene* sc, Workspace& ws, uint32_t npix, int32_t
         spass = default_pass_size(npix, max_depth, sc->pass_budget);
         if (halve_call) spass = std::min(spass, (spp + 1u) / 2u);
         spass = std::max(1u, std::min(spass, spp));
+        spass = (spp + (spp + spass - 1u) / spass - 1u) / ((spp + spass - 1u) / spass);   // the same number of passes, of near-equal size (25 spp at 12 per pass: 9 + 8 + 8, not 12 + 12 + 1)
         if ((uint64_t)npix * spass > 0x7FFFFF00ull) return fail(RT_ERR_BAD_ARG, "samples_per_pass * pixels too large");
         int rc = ws_ensure(sc, ws, npix * spass, max_depth);
         if (rc != RT_ERR_OOM || step >= 5 || default_pass_size(npix, max_depth, sc->pass_budget) == 1) return rc;
