@@ -183,6 +183,7 @@ struct rt_scene {
     double* d_cert_planes = nullptr;
     uint32_t* d_cert_plane_off = nullptr;
     uint32_t* d_cert_plane_leaf = nullptr;
+    InstCull* d_inst_cull = nullptr; InstPlane* d_inst_planes = nullptr;
     SceneDev dev{};
     rt_blob_header hdr{};
     std::vector<rt_prim> host_prims;
@@ -286,6 +287,9 @@ static void launch_trace(rt_scene* sc, unsigned long long* lstats, uint32_t lcap
     if (n_bound == 0) return;
     SceneDev dv = sc->dev;   // this launch's copy of the kernel argument
     dv.count_steps = count_steps ? 1u : 0u;
+#ifdef RT_ORACLE_BEST
+    if (tune("RT_TUNE_INST_EXPERIMENT", 0)) dv.oracle_best = (uint32_t)tune("RT_TUNE_INST_EXPERIMENT", 0);
+#endif
     const uint32_t wpb = RT_TRACE_BLOCK / 64u;
     const uint64_t n_waves = (lanes & RT_LANES_AUTO) ? waves_auto(n_bound) : ((uint64_t)n_bound + lanes - 1u) / lanes;
     const dim3 grid((uint32_t)((n_waves + wpb - 1u) / wpb));  // waves of `lanes` rays, RT_TRACE_BLOCK / 64 waves per block
@@ -439,6 +443,13 @@ static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bo
         if (use_walk && bounce >= 1) { int rc = launch_walk(sc, ws, st, ws.queue[cur], c_in, live, ws.pb.rays, 0.001, 100000.0, ws.pb.hit, nullptr, 1u, false); if (rc != RT_OK) return rc; }
         else launch_trace(sc, ws.stats, ws.cap, st, count_tests, ws.queue[cur], c_in, live, ws.pb.rays, 0.001, 100000.0, nullptr, nullptr, nullptr, small ? lanes_auto() : 64u, 1u, ws.pb.hit, false, nullptr, count_steps);  // integrator.rs:38
         if (!small) tm.end();
+#ifdef RT_ORACLE_BEST
+        if (tune("RT_TUNE_ORACLE_BEST", 0)) {   // the same launch again, every walk starting from the hit distance the first one found
+            SceneDev keep = sc->dev; sc->dev.oracle_best = 1u;
+            launch_trace(sc, ws.stats, ws.cap, st, count_tests, ws.queue[cur], c_in, live, ws.pb.rays, 0.001, 100000.0, nullptr, nullptr, nullptr, 64u, 1u, ws.pb.hit, false, nullptr, count_steps);
+            sc->dev = keep;
+        }
+#endif
         if (cap && !cap->shadow && (uint32_t)bounce == cap->bounce) return capture_queue(ws, st, ws.queue[cur], live, ws.pb.rays, ws.pb.hit, nullptr, *cap);
         const bool mis_shadow = integrator == RT_INT_MIS && sc->dev.n_lights > 0;
         const bool last_bounce = bounce + 1 >= max_depth;
@@ -586,6 +597,7 @@ struct ScenePrep {
     double box_abs_max = 0.0;
     uint32_t root_off = 0;
     PruneHost prune;
+    std::vector<InstCull> inst_cull; std::vector<InstPlane> inst_planes;   // scenes with BVHNode instances: whole-instance strict pruning (inst_line_misses)
 };
 static int prepare_scene(const void* blob, uint64_t nbytes, ScenePrep& P) {
     if (nbytes < sizeof(rt_blob_header)) return fail(RT_ERR_BAD_BLOB, "blob smaller than its header");
@@ -690,6 +702,13 @@ static int prepare_scene(const void* blob, uint64_t nbytes, ScenePrep& P) {
         return nd.prim1 == RT_NONE || (geom[nd.prim1].kind == RT_PRIM_SPHERE && geom[nd.prim0].xform == geom[nd.prim1].xform);
     };
     build_prune(h, nodes, geom, is_tri2, is_sph2, P.prune);
+    if (P.has_instances) build_inst_cull(h, nodes, prims, geom, P.inst_cull, P.inst_planes);
+    if (tune("RT_TUNE_DEBUG", 0)) {
+        size_t ok = 0; for (auto& c : P.inst_cull) ok += c.ok;
+        fprintf(stderr, "[rt] instances with a cull box: %zu of %zu prims, %zu planes\n", ok, P.inst_cull.size(), P.inst_planes.size());
+        for (auto& c : P.inst_cull) if (c.ok) fprintf(stderr, "[rt]   box %g %g %g .. %g %g %g tau_coef %g radius %g planes %u\n", c.lo[0], c.lo[1], c.lo[2], c.hi[0], c.hi[1], c.hi[2], c.tau_coef, c.radius, c.n_planes);
+    }
+
     // ranges: the scene-level array and every instance sub-array (validated above: disjoint, links stay inside);
     // range_end[i] = end index of the range node i belongs to, ends_here[e] = some range ends before node e
     std::vector<uint32_t> range_end((size_t)h.n_nodes, h.n_nodes);
@@ -949,7 +968,15 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
         if (e == hipSuccess) e = hipMalloc((void**)&sc->d_cert_plane_leaf, std::max<size_t>(pr.plane_leaf.size(), 1) * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMemcpy(sc->d_cert_plane_leaf, pr.plane_leaf.data(), pr.plane_leaf.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     }
+    if (!P.inst_cull.empty()) {
+        if (e == hipSuccess) e = hipMalloc((void**)&sc->d_inst_cull, P.inst_cull.size() * sizeof(InstCull));
+        if (e == hipSuccess) e = hipMemcpy(sc->d_inst_cull, P.inst_cull.data(), P.inst_cull.size() * sizeof(InstCull), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void**)&sc->d_inst_planes, std::max<size_t>(P.inst_planes.size(), 1) * sizeof(InstPlane));
+        if (e == hipSuccess) e = hipMemcpy(sc->d_inst_planes, P.inst_planes.data(), P.inst_planes.size() * sizeof(InstPlane), hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) {
+        if (sc->d_inst_cull) (void)hipFree(sc->d_inst_cull);
+        if (sc->d_inst_planes) (void)hipFree(sc->d_inst_planes);
         if (sc->dblob) (void)hipFree(sc->dblob);
         if (sc->d_mat_uses_uv) (void)hipFree(sc->d_mat_uses_uv);
         if (sc->d_stream) (void)hipFree(sc->d_stream);
@@ -974,6 +1001,8 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     v.materials = (const rt_material*)(d + h.off_materials); v.textures = (const rt_texture*)(d + h.off_textures);
     v.texels = d + h.off_texels; v.lights = (const rt_light*)(d + h.off_lights);
     v.mat_uses_uv = sc->d_mat_uses_uv;
+    v.inst_cull = sc->d_inst_cull; v.inst_planes = sc->d_inst_planes;
+    if (tune("RT_TUNE_INST_CULL", 1) == 0) v.inst_cull = nullptr;   // A/B
     v.stream = sc->d_stream; v.root_off = P.root_off_prod;
     v.end_off = P.end_off_prod[h.root_end]; v.end_off_full = P.end_off[h.root_end];
     v.stream_full = sc->d_stream_full; v.node_off_full = sc->d_node_off_full; v.root_off_full = P.root_off;
@@ -1054,6 +1083,8 @@ int rt_scene_destroy(rt_scene* sc) {
     if (sc->d_cert_planes) (void)hipFree(sc->d_cert_planes);
     if (sc->d_cert_plane_off) (void)hipFree(sc->d_cert_plane_off);
     if (sc->d_cert_plane_leaf) (void)hipFree(sc->d_cert_plane_leaf);
+    if (sc->d_inst_cull) (void)hipFree(sc->d_inst_cull);
+    if (sc->d_inst_planes) (void)hipFree(sc->d_inst_planes);
     sc->ctx->live_scenes -= 1;
     delete sc;
     return RT_OK;

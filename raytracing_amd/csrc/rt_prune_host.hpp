@@ -260,3 +260,56 @@ static void build_prune(const rt_blob_header& h, const rt_node* nodes, const rt_
     R.box_abs_max = babs;
     R.on = true;
 }
+
+// Per INSTANCE primitive: what inst_line_misses (rt_trace.hip.h) needs to skip the whole sub-array.  An instance qualifies when every
+// primitive of its sub-array is a triangle in the sub-array's own space (prepare_scene has validated: no nested transform) with finite,
+// moderate coordinates and a shape factor of at least RT_PRUNE_MIN_SHAPE, and there are at most RT_INST_CULL_MAX_TRIS of them.
+// Constants as in build_prune: tau_coef = 2^-21 / shape_min, delta_coef = 2 tau_coef, radius = max |v0|_inf + max edge 1-norm.
+static void build_inst_cull(const rt_blob_header& h, const rt_node* nodes, const rt_prim* prims, const rt_geom* geom, std::vector<InstCull>& cull, std::vector<InstPlane>& planes) {
+    cull.assign((size_t)h.n_prims, InstCull{});
+    for (uint32_t p = 0; p < h.n_prims; ++p) {
+        if (prims[p].kind != RT_PRIM_INSTANCE) continue;
+        InstCull c{};
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        double shape_min = 1.0, e_max = 0.0, v_max = 0.0;
+        bool good = true;
+        std::vector<uint32_t> tris;
+        for (uint32_t i = prims[p].index; i < prims[p].sub_end && good; ++i)
+            for (uint32_t q : {nodes[i].prim0, nodes[i].prim1}) {
+                if (q == RT_NONE) continue;
+                if (geom[q].kind != RT_PRIM_TRIANGLE || geom[q].xform != RT_NONE) { good = false; break; }
+                if (std::find(tris.begin(), tris.end(), q) == tris.end()) tris.push_back(q);   // a 1-object leaf lists its primitive once; be safe about repeats
+                if (tris.size() > RT_INST_CULL_MAX_TRIS) { good = false; break; }
+            }
+        good = good && !tris.empty();
+        const uint32_t first_plane = (uint32_t)planes.size();
+        for (size_t t = 0; t < tris.size() && good; ++t) {
+            const double* v0 = geom[tris[t]].d; const double* e1 = v0 + 3; const double* e2 = v0 + 6;
+            for (int k = 0; k < 9; ++k) good = good && std::isfinite(v0[k]);
+            const double E1 = std::fabs(e1[0]) + std::fabs(e1[1]) + std::fabs(e1[2]), E2 = std::fabs(e2[0]) + std::fabs(e2[1]) + std::fabs(e2[2]);
+            const double V = std::max(std::max(std::fabs(v0[0]), std::fabs(v0[1])), std::fabs(v0[2]));
+            good = good && E1 >= 0x1p-100 && E1 <= 0x1p100 && E2 >= 0x1p-100 && E2 <= 0x1p100 && V <= 0x1p100;
+            if (!good) break;
+            const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+            const double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            const double shape = len / (E1 * E2);
+            good = good && shape >= RT_PRUNE_MIN_SHAPE * (1.0 + 0x1p-20);
+            if (!good) break;
+            shape_min = std::min(shape_min, shape); e_max = std::max(e_max, std::max(E1, E2)); v_max = std::max(v_max, V);
+            InstPlane pl;
+            for (int k = 0; k < 3; ++k) pl.n[k] = n[k] / len;
+            pl.q = v0[0] * pl.n[0] + v0[1] * pl.n[1] + v0[2] * pl.n[2];
+            planes.push_back(pl);
+            for (int k = 0; k < 3; ++k) {   // vertices v0, v0 + e1, v0 + e2 (sums rounded outward)
+                const double a = v0[k] + e1[k], b = v0[k] + e2[k];
+                lo[k] = std::min(lo[k], std::min(v0[k], std::min(std::nextafter(a, -INFINITY), std::nextafter(b, -INFINITY))));
+                hi[k] = std::max(hi[k], std::max(v0[k], std::max(std::nextafter(a, INFINITY), std::nextafter(b, INFINITY))));
+            }
+        }
+        if (!good) { planes.resize(first_plane); continue; }
+        for (int k = 0; k < 3; ++k) { c.lo[k] = lo[k]; c.hi[k] = hi[k]; }
+        c.tau_coef = 0x1p-21 / shape_min; c.delta_coef = 0x1p-20 / shape_min; c.radius = v_max + e_max;
+        c.ok = 1u; c.n_planes = (uint32_t)(planes.size() - first_plane); c.first_plane = first_plane;
+        cull[p] = c;
+    }
+}

@@ -15,7 +15,16 @@ namespace rt {
 template <class T> using cptr = const RT_CONST T*;
 template <class T> RT_DEV cptr<T> as_const(const T* p) { return (cptr<T>)(uintptr_t)p; }
 
+// Strict pruning of a whole BVHNode instance (rt_trace.hip.h, inst_line_misses): per INSTANCE primitive, the box of the triangles of its
+// sub-array in their own (object) space, the error constants of DESIGN.md section 5 for that space, and the (unit normal, plane offset)
+// of every triangle -- few enough for the certificate to be a plain loop.  ok == 0: the instance is always walked.
+struct InstCull { double lo[3], hi[3]; double tau_coef, delta_coef, radius; uint32_t ok, n_planes, first_plane, pad; };
+struct InstPlane { double n[3], q; };
+#define RT_INST_CULL_MAX_TRIS 64u
+
 struct SceneDev {
+    const InstCull* inst_cull;      // [n_prims] (entries of INSTANCE primitives are meaningful), or null: scene without instances
+    const InstPlane* inst_planes;
     const rt_node* nodes;
     const rt_prim* prims;
     const rt_geom* geom;  // parallel to prims
@@ -49,6 +58,7 @@ struct SceneDev {
     uint32_t n_nodes, boxes_finite;
     uint32_t translate_xf;  // a transform whose inverse is exactly identity + a translation with three finite non-zero components (RT_NONE: none):
                             // for rays without zero / non-finite components apply_xform<true> adds the translation instead of multiplying the matrix out
+    uint32_t oracle_best;   // experiment builds only (-DRT_ORACLE_BEST): start every walk from the hit a previous launch left in out_hit (launch_trace's copy)
     uint32_t count_steps;   // per launch (launch_trace's copy): k_trace adds its waves' record steps to stats[15] -- one same-address atomic per wave, 5 % of the frame, so only on request
     float sort_min[3], sort_scale[3];  // origin quantisation grid of the ray-sorting key
 };

@@ -466,6 +466,44 @@ RT_DEV void apply_xform(const SceneDev& sc, uint32_t xform, const RayS& ray, d3&
     }
 }
 
+// Strict pruning at the level of a whole instance (cornell: six Transformed(BVHNode::from_mesh(cube)) objects, main.rs:161-188).  The
+// reference enters the sub-BVH whenever its weak per-axis test passes the sub-array's root box -- for a ray inside the room that is
+// most of the six -- and then tests boxes and triangles that cannot be hit.  By Claim 2 a triangle the reference
+// ACCEPTS has the ray's line within tau of it, unless the ray is nearly parallel to the triangle's plane and starts within delta of
+// that plane.  So when (o, d) -- the ray in the instance's object space, the bits the reference computes (transform.rs:25-32) -- is not
+// suspect for any triangle of the instance and its LINE misses the box of those triangles inflated by tau, the sub-walk accepts
+// nothing: it leaves the running best, every later decision and the final hit unchanged, and is skipped.  Everything is f64 here (the
+// slack 2^-40 relative covers the roundings of this test itself).  The counting kernel walks anyway and counts accepts after a "miss".
+RT_DEV bool inst_line_misses(const SceneDev& sc, uint32_t p, d3 o, d3 d, d3 inv) {   // inv = 1 / d, the divisions the sub-walk needs anyway (bounding_box.rs:29)
+    if (sc.inst_cull == nullptr) return false;
+    cptr<InstCull> ic = as_const(sc.inst_cull) + p;
+    if (ic->ok == 0u) return false;
+    const double ad[3] = {fabs(d.x), fabs(d.y), fabs(d.z)}, oo[3] = {o.x, o.y, o.z}, ii[3] = {inv.x, inv.y, inv.z};
+    const double D = fmax(fmax(ad[0], ad[1]), ad[2]), O = fmax(fmax(fabs(o.x), fabs(o.y)), fabs(o.z));
+    if (!(D >= 0x1p-100 && D <= 0x1p100 && O <= 0x1p100)) return false;   // also NaN
+    const double tau = ic->tau_coef * (O + ic->radius) * (1.0 + 0x1p-20), delta = ic->delta_coef * (O + ic->radius), thr = RT_CERT_EPS * D;
+    double tn = -__builtin_inf(), tf = __builtin_inf();
+    bool miss = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double lo = ic->lo[k] - tau, hi = ic->hi[k] + tau;
+        if (ad[k] >= 0x1p-200 && fabs(ii[k]) <= 0x1p300) {   // 1/d finite and non-zero: slab parameters by multiplication (errors far inside the slack)
+            const double t0 = (lo - oo[k]) * ii[k], t1 = (hi - oo[k]) * ii[k];
+            const double s = 0x1p-40 * ((fabs(lo) + fabs(hi)) + fabs(oo[k])) * fabs(ii[k]);
+            tn = fmax(tn, fmin(t0, t1) - s); tf = fmin(tf, fmax(t0, t1) + s);
+        } else if (ad[k] < 0x1p-200) miss = miss || oo[k] < lo || oo[k] > hi;   // parallel to the slab and outside it: the line never enters
+    }
+    miss = miss || tn > tf;
+    if (!miss) return false;
+    cptr<InstPlane> pl = as_const(sc.inst_planes) + ic->first_plane;
+    const uint32_t np = ic->n_planes;
+    for (uint32_t i = 0; i < np; ++i) {   // suspect for a triangle: nearly parallel to its plane AND within delta of it (then the reference may accept garbage)
+        const double nx = pl[i].n[0], ny = pl[i].n[1], nz = pl[i].n[2];
+        if (fabs(d.x * nx + d.y * ny + d.z * nz) < thr && fabs((o.x * nx + o.y * ny + o.z * nz) - pl[i].q) <= delta) return false;
+    }
+    return true;
+}
+
 // One primitive against the wave's rays (exact f64); (xo, xd) is the ray already in the primitive's space.
 // Returns true if the lane's closest hit changed.
 template <int LEVEL, bool COUNT, bool INST, class HIT>
@@ -491,10 +529,35 @@ RT_DEV bool test_prim(const SceneDev& sc, uint32_t p, const GeomS& g, bool pass,
         double t;
         if (pass && rect_hit(g.d[0], g.d[1], g.d[2], g.d[3], g.d[4], xo, xd, t_min, h.best, t)) { h.best = t; h.prim = p; h.inst = inst_prim; changed = true; }
     } else if constexpr (LEVEL == 0 && INST) {  // RT_PRIM_INSTANCE: BVHNode object (optionally under a Transformed), main.rs:161-188
-        RayInRegisters sub; sub.r.o = xo; sub.r.d = xd; sub.r.time = ray.time; sub.rinv = mk(1.0 / xd.x, 1.0 / xd.y, 1.0 / xd.z);
-        const double before = h.best;
-        traverse<1, COUNT, INST, RayInRegisters, HIT>(sc, (uint32_t)g.d[0], sub, h, pass, t_min, p, cnt);  // first node of the sub-array
-        changed = (double)h.best != before;
+#ifdef RT_ORACLE_BEST
+        if (sc.oracle_best == 1u) return false;
+#endif
+        const d3 xinv = mk(1.0 / xd.x, 1.0 / xd.y, 1.0 / xd.z);
+        const bool culled = pass && inst_line_misses(sc, p, xo, xd, xinv);
+        // BVHNode::hit starts with its own box (bvh.rs:92-94): decided here, in the reference's arithmetic, before the sub-walk sets anything up --
+        // after a first hit most instances fail it (their slab lies beyond the running best), and setting a sub-walk up costs as much as walking it
+        bool root_ok = true;
+        if (!COUNT) {
+            cptr<rt_node> sub_nodes = as_const(sc.nodes);
+            const RT_CONST rt_node& rn = sub_nodes[(uint32_t)g.d[0]];
+            const double best = h.best;
+            const bool plain_ray = ray_is_plain(xo, xinv) && t_min <= best && sc.boxes_finite != 0u;
+            root_ok = (rn.flags & RT_NODE_NO_BOX) != 0u || !plain_ray ||   // NaN-capable rays: the sub-walk decides with the literal form
+                      (box_axis_fast(rn.bmin[0], rn.bmax[0], xo.x, xinv.x, t_min, best) & box_axis_fast(rn.bmin[1], rn.bmax[1], xo.y, xinv.y, t_min, best) &
+                       box_axis_fast(rn.bmin[2], rn.bmax[2], xo.z, xinv.z, t_min, best));
+        }
+        bool enter = COUNT ? pass : (pass && !culled && root_ok);
+#ifdef RT_ORACLE_BEST   /* experiment build: where do an instance's instructions go?  1: no instance is entered; 2: everything but the sub-walk */
+        if (sc.oracle_best == 2u) enter = false;
+#endif
+        if (__builtin_amdgcn_ballot_w64(enter) != 0ull) {   // wave-uniform: nobody left -> the sub-array is not walked at all
+            RayInRegisters sub; sub.r.o = xo; sub.r.d = xd; sub.r.time = ray.time; sub.rinv = xinv;
+            const double before = h.best;
+            traverse<1, COUNT, INST, RayInRegisters, HIT>(sc, (uint32_t)g.d[0], sub, h, enter, t_min, p, cnt);  // first node of the sub-array
+            changed = (double)h.best != before;
+            if (COUNT) cnt.bad += (changed && culled) ? 1u : 0u;   // an accept inside an instance the cull would have skipped
+        }
+        RT_RECONVERGE();
     }
     return changed;
 }
@@ -921,6 +984,9 @@ __global__ __launch_bounds__(RT_TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(
     LaneHit h;
     h.best.p = (lptr<volatile double>)&lds_best[threadIdx.x]; h.prim.p = (lptr<volatile uint32_t>)&lds_prim[threadIdx.x]; h.inst.p = (lptr<volatile uint32_t>)&lds_inst[threadIdx.x];
     h.best = t_max; h.prim = RT_NONE; h.inst = RT_NONE;
+#ifdef RT_ORACLE_BEST   /* experiment: what would KNOWING the hit distance be worth?  The walk starts from the t a previous launch found */
+    if (sc.oracle_best != 0u && out_hit && valid) { const double b = out_hit[slot].t; if (b == b) h.best = b * (1.0 + 0x1p-30) + 0x1p-30; }
+#endif
     LaneCount cnt; cnt.box = cnt.tri = cnt.sph = cnt.bad = 0; cnt.pruned_until = 0; cnt.uncertified = 0; cnt.wsteps = 0;
 #ifdef RT_TRACE_DIAG
     cnt.steps = cnt.leaf_steps = cnt.cyc_wait = cnt.lane_steps = cnt.exact_box = cnt.exact_tri = 0; cnt.cyc_xbox = cnt.cyc_xtri = cnt.cyc_setup = cnt.cyc_leaf = cnt.leaf_open = 0; cnt.cyc_total = __builtin_readcyclecounter(); cnt.diag_flags = 0;
