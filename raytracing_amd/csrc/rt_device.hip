@@ -390,6 +390,7 @@ static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bo
     PathBuffers pbk = ws.pb;   // what the kernels see: signatures only for rt_sample_radiance_sig
     if (!want_sig) pbk.sig = nullptr;
     else HIP_OK(hipMemsetAsync(pbk.sig, 0, (size_t)n * sizeof(unsigned long long), st));
+    const bool compact = !(integrator == RT_INT_MIS && sc->dev.n_lights > 0);   // no light sample can occur: 32-byte bounce records (rt_shade.hip.h)
     const bool use_walk = sc->walk_ok && !count_tests && lane_walk;   // opt-in (RT_RENDER_LANE_WALK): bounce >= 1 and shadow rays by the per-lane walk (k_walk)
     const uint32_t npix = width * height;
     if (max_depth > ws.depth && max_depth > 1) return fail(RT_ERR_BAD_ARG, "run_paths: workspace sized for a smaller depth");
@@ -473,12 +474,11 @@ static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bo
         // shade appends survivors compactly: to the raw queues with their coherence keys when the next bounce is sorted, else straight to the next queues
         const bool sorted = sort_rays && !small;
         const dim3 sgrid((live + RT_SHADE_BLOCK * RT_SHADE_TILES - 1u) / (RT_SHADE_BLOCK * RT_SHADE_TILES));
-        if (sorted)
-            hipLaunchKernelGGL(k_shade, sgrid, dim3(RT_SHADE_BLOCK), 0, st, sc->dev, pbk, ws.queue[cur], order, c_in, (uint32_t)bounce, max_depth, integrator,
-                               seed, ws.raw_queue, ws.raw_keys, c_next, ws.raw_squeue, ws.raw_skeys, c_shadow);
-        else
-            hipLaunchKernelGGL(k_shade_dense, sgrid, dim3(RT_SHADE_BLOCK), 0, st, sc->dev, pbk, ws.queue[cur], order, c_in, (uint32_t)bounce, max_depth, integrator,
-                               seed, ws.queue[nxt], (uint32_t*)nullptr, c_next, ws.shadow_queue, (uint32_t*)nullptr, c_shadow);
+#define RT_LAUNCH_SHADE(KERNEL, NQ, NK, SQ, SK) hipLaunchKernelGGL(KERNEL, sgrid, dim3(RT_SHADE_BLOCK), 0, st, sc->dev, pbk, ws.queue[cur], order, c_in, (uint32_t)bounce, max_depth, integrator, \
+                                                                   seed, NQ, NK, c_next, SQ, SK, c_shadow)
+        if (sorted) { if (compact) RT_LAUNCH_SHADE(k_shade<true>, ws.raw_queue, ws.raw_keys, ws.raw_squeue, ws.raw_skeys); else RT_LAUNCH_SHADE(k_shade<false>, ws.raw_queue, ws.raw_keys, ws.raw_squeue, ws.raw_skeys); }
+        else { if (compact) RT_LAUNCH_SHADE(k_shade_dense<true>, ws.queue[nxt], (uint32_t*)nullptr, ws.shadow_queue, (uint32_t*)nullptr); else RT_LAUNCH_SHADE(k_shade_dense<false>, ws.queue[nxt], (uint32_t*)nullptr, ws.shadow_queue, (uint32_t*)nullptr); }
+#undef RT_LAUNCH_SHADE
         uint32_t next_live = live, shadow_live = live;   // small queues: bounds
         if (small) {
             if ((bounce - lag_from) % (int32_t)RT_LAG == 0) {
@@ -519,7 +519,7 @@ static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bo
     if (shadow_pending) HIP_OK(hipStreamWaitEvent(st, ws.ev_shadowed, 0));   // k_unwind reads the visibility results
     if (lag_from >= 0) tm.end();   // CAT_TAIL (the visibility launches on the side stream have been waited for)
     tm.begin(CAT_OTHER);
-    hipLaunchKernelGGL(k_unwind, grid_for(n), dim3(256), 0, st, pbk, n);
+    if (compact) hipLaunchKernelGGL(k_unwind<true>, grid_for(n), dim3(256), 0, st, pbk, n); else hipLaunchKernelGGL(k_unwind<false>, grid_for(n), dim3(256), 0, st, pbk, n);
     hipLaunchKernelGGL(k_sum_shadow_counts, dim3(1), dim3(64), 0, st, ws.counts, (uint32_t)max_depth, ws.stats + RT_STAT_SHADOW_RAYS);   // rt_stats.shadow_rays, whichever mode the bounces ran in
     tm.end();
     launches += 2;

@@ -46,6 +46,11 @@ __global__ __launch_bounds__(256) void k_raygen(rt_camera cam, uint32_t width, u
 //   not visible / no light sample:  L = (brdf*cos*L_next)/pdf              (integrator.rs:62-66,164-168,224,291,361)
 //   light visible (MIS):            L = (brdf*cos*L_next*w)/pdf + C_l      (integrator.rs:138-154), w gated by L_next >= .001
 enum { REC_BRDF_X = 0, REC_BRDF_Y, REC_BRDF_Z, REC_COS, REC_PDF, REC_W, REC_CL_X, REC_CL_Y, REC_CL_Z, REC_T_LIGHT, REC_T_SHADOW, REC_FIELDS, REC_STRIDE = 12 };
+// COMPACT records (every integrator but MIS in a scene with lights: no light sample, no weight, no visibility test): only the first line of the table above can
+// occur, so a record is the 32-byte block { brdf*cos (3), pdf } -- the product k_unwind would form first anyway, hence the same bits -- at a stride of 4 doubles
+// in the same buffer.  k_shade / k_unwind are built in both forms; shading is half-way to the HBM roofline on the scenes without a BVH to walk, and a record
+// was 80 of the 164 bytes it writes per ray.
+enum { CREC_A_X = 0, CREC_A_Y, CREC_A_Z, CREC_PDF, CREC_STRIDE = 4 };
 
 struct PathBuffers {
     double* rays;        // [7][cap]
@@ -220,6 +225,7 @@ __global__ __launch_bounds__(256) void k_bin_scatter(const uint8_t* __restrict__
                         uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_keys, uint32_t* __restrict__ next_count,                                    \
                         uint32_t* __restrict__ shadow_queue, uint32_t* __restrict__ shadow_keys, uint32_t* __restrict__ shadow_count
 #define RT_SHADE_ARGS sc, pb, queue, order, n_ptr, bounce, max_depth, integrator, seed, next_queue, next_keys, next_count, shadow_queue, shadow_keys, shadow_count
+template <bool COMPACT>
 RT_DEV void shade_block(const SceneDev& sc, const PathBuffers& pb, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ order, const uint32_t* __restrict__ n_ptr,
                         uint32_t bounce, int32_t max_depth, int32_t integrator, uint64_t seed,
                         uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_keys, uint32_t* __restrict__ next_count,
@@ -250,6 +256,7 @@ RT_DEV void shade_block(const SceneDev& sc, const PathBuffers& pb, const uint32_
         const uint32_t prim = ph.prim;
         d3 terminal = mk(0.0, 0.0, 0.0);
         bool done = false;
+        uint32_t n_records = bounce;   // records this path holds when it ends here: one per level before this one, plus this level's if it ends by depth
         HitRecord hr;
         unsigned long long sg = 0ull;   // this level's events (rt_math.h "path signatures"); only summed when pb.sig is set
         const bool want_sig = pb.sig != nullptr;
@@ -358,15 +365,21 @@ RT_DEV void shade_block(const SceneDev& sc, const PathBuffers& pb, const uint32_
                 if (want_sig && material_pdf.kind == PDF_DIELECTRIC)   // reflected (1) or refracted (0): pdf.rs:167-173
                     sg += sig_hash(bounce, SIG_DELTA, (gen_dir.x == material_pdf.a.x && gen_dir.y == material_pdf.a.y && gen_dir.z == material_pdf.a.z) ? 1ull : 0ull);
                 if (!done) {
-                    double* rec = pb.records + ((size_t)bounce * cap + path) * REC_STRIDE;
-                    rec[REC_BRDF_X] = brdf.x; rec[REC_BRDF_Y] = brdf.y; rec[REC_BRDF_Z] = brdf.z;
-                    rec[REC_COS] = cos_theta; rec[REC_PDF] = pdf; rec[REC_W] = w;
-                    rec[REC_CL_X] = c_l.x; rec[REC_CL_Y] = c_l.y; rec[REC_CL_Z] = c_l.z;
-                    rec[REC_T_LIGHT] = t_light;
-                    pb.info[path].nb = bounce + 1u;
+                    if (COMPACT) {
+                        const d3 a = brdf * cos_theta;   // k_unwind: ((brdf * cos) * L) / pdf
+                        double4* rec = (double4*)(pb.records + ((size_t)bounce * cap + path) * CREC_STRIDE);
+                        *rec = make_double4(a.x, a.y, a.z, pdf);
+                    } else {
+                        double* rec = pb.records + ((size_t)bounce * cap + path) * REC_STRIDE;
+                        rec[REC_BRDF_X] = brdf.x; rec[REC_BRDF_Y] = brdf.y; rec[REC_BRDF_Z] = brdf.z;
+                        rec[REC_COS] = cos_theta; rec[REC_PDF] = pdf; rec[REC_W] = w;
+                        rec[REC_CL_X] = c_l.x; rec[REC_CL_Y] = c_l.y; rec[REC_CL_Z] = c_l.z;
+                        rec[REC_T_LIGHT] = t_light;
+                    }
                     if ((int32_t)(bounce + 1u) >= max_depth) {  // next level has depth <= 0: returns 0 without tracing (integrator.rs:33-35)
                         terminal = mk(0.0, 0.0, 0.0);
                         done = true;
+                        n_records = bounce + 1u;
                     } else {
                         double4* n4 = (double4*)(pb.rays + (size_t)path * RT_RAY_STRIDE);
                         n4[0] = make_double4(hr.point.x, hr.point.y, hr.point.z, out_dir.x); n4[1] = make_double4(out_dir.y, out_dir.z, ray.time, 0.0);
@@ -377,7 +390,9 @@ RT_DEV void shade_block(const SceneDev& sc, const PathBuffers& pb, const uint32_
             }
         }
         if (want_sig) pb.sig[path] += sg;
-        if (done) { pb.terminal[(size_t)path * 4u + 0] = terminal.x; pb.terminal[(size_t)path * 4u + 1] = terminal.y; pb.terminal[(size_t)path * 4u + 2] = terminal.z; }
+        // a path ends exactly once: its terminal radiance and its record count go out together (one 32-byte block; the count used to be a
+        // scattered 4-byte write per shaded ray into the path's info block)
+        if (done) { double4* tb = (double4*)(pb.terminal + (size_t)path * 4u); *tb = make_double4(terminal.x, terminal.y, terminal.z, (double)n_records); }
     }
     st_path[tile][threadIdx.x] = path; st_nkey[tile][threadIdx.x] = next_key; st_skey[tile][threadIdx.x] = shadow_key;
     st_flag[tile][threadIdx.x] = (uint8_t)((want_next ? 1u : 0u) | (want_shadow ? 2u : 0u));
@@ -417,19 +432,27 @@ RT_DEV void shade_block(const SceneDev& sc, const PathBuffers& pb, const uint32_
 // issue slots, where a faster k_shade only hands its time to the k_trace of the other lane.  k_shade_dense: 4 waves per SIMD (128 VGPRs + 88 B of
 // scratch), a third faster on its own -- for the small scenes (no ray sorting: earth, broken cube), where shading is the larger half of the frame:
 // +4 % there, -2 % on the pagoda.
-__global__ __launch_bounds__(RT_SHADE_BLOCK) RT_SHADE_OCCUPANCY void k_shade(RT_SHADE_PARAMS) { shade_block(RT_SHADE_ARGS); }
-__global__ __launch_bounds__(RT_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_shade_dense(RT_SHADE_PARAMS) { shade_block(RT_SHADE_ARGS); }
+template <bool COMPACT> __global__ __launch_bounds__(RT_SHADE_BLOCK) RT_SHADE_OCCUPANCY void k_shade(RT_SHADE_PARAMS) { shade_block<COMPACT>(RT_SHADE_ARGS); }
+template <bool COMPACT> __global__ __launch_bounds__(RT_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_shade_dense(RT_SHADE_PARAMS) { shade_block<COMPACT>(RT_SHADE_ARGS); }
 
 // ------------------------------------------------------------------------------------------------
 // k_unwind / k_accumulate / k_resolve
 // ------------------------------------------------------------------------------------------------
+template <bool COMPACT>
 __global__ __launch_bounds__(256) void k_unwind(PathBuffers pb, uint32_t n) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const size_t cap = pb.cap;
-    d3 L = mk(pb.terminal[(size_t)p * 4u + 0], pb.terminal[(size_t)p * 4u + 1], pb.terminal[(size_t)p * 4u + 2]);
+    const double4 tb = *(const double4*)(pb.terminal + (size_t)p * 4u);
+    d3 L = mk(tb.x, tb.y, tb.z);
     unsigned long long sg = 0ull;
-    for (int k = (int)pb.info[p].nb - 1; k >= 0; --k) {
+    for (int k = (int)tb.w - 1; k >= 0; --k) {
+        d3 e = mk(0.0, 0.0, 0.0);  // emitted of a scattering material
+        if (COMPACT) {
+            const double4 r = *(const double4*)(pb.records + ((size_t)k * cap + p) * CREC_STRIDE);
+            L = e + (mk(r.x, r.y, r.z) * L) / r.w;
+            continue;
+        }
         const double* rec = pb.records + ((size_t)k * cap + p) * REC_STRIDE;
         d3 brdf = mk(rec[REC_BRDF_X], rec[REC_BRDF_Y], rec[REC_BRDF_Z]);
         double cos_theta = rec[REC_COS], pdf = rec[REC_PDF], t_light = rec[REC_T_LIGHT];
@@ -439,7 +462,6 @@ __global__ __launch_bounds__(256) void k_unwind(PathBuffers pb, uint32_t n) {
             visible = (t_shadow == t_shadow) && !(fabs(t_shadow - t_light) > 0.0001);
             sg += sig_hash((uint32_t)k, SIG_VIS, visible ? 1ull : 0ull);
         }
-        d3 e = mk(0.0, 0.0, 0.0);  // emitted of a scattering material
         if (visible) {
             bool has_light = L.x >= 0.001 && L.y >= 0.001 && L.z >= 0.001;  // integrator.rs:119-121
             sg += sig_hash((uint32_t)k, SIG_GATE, has_light ? 1ull : 0ull);
