@@ -76,6 +76,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"))  # gloo + --renderer: the CPU test of the N-rank plumbing
+    # gloo collectives (staged through host memory) around the REAL renderer, every rank on GPU (local rank mod device count): the N-rank path end to end
+    # on a box with fewer GPUs than ranks, where RCCL refuses two ranks on one device (tests/test_gpu_multirank.py); never a measurement
+    ap.add_argument("--gloo-gpu", action="store_true")
     ap.add_argument("--renderer", default="")                     # python file with make_renderer(args, rank, world, device, distributed_module): replaces the HIP renderer (tests)
     # rehearsal on ONE GPU of what rank r of an N-rank run does: "r/N" -> this process renders rank r's share of the frame (same jobs,
     # same sample indices), with no process group; the line then carries `rehearsal` and is not a scaling measurement
@@ -258,11 +261,15 @@ def main():
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
         return 2
-    on_gpu = args.backend == "nccl"
+    if args.gloo_gpu:
+        args.backend = "gloo"
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    on_gpu = args.backend == "nccl" or args.gloo_gpu
     dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+    coll_dev = dev if args.backend == "nccl" else torch.device("cpu")    # where the collectives' tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if on_gpu:
+        if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -278,7 +285,7 @@ def main():
         R = mod.make_renderer(args, rank, world, dev, rtd)
         W, H = R.W, R.H
     else:
-        R = HipRenderer(args, rank, world, local_rank, dev, rtd)
+        R = HipRenderer(args, rank, world, local_rank, coll_dev, rtd)
     accum = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     spp_step = args.spp_per_step
     frame_spp = args.steps * spp_step                      # the frame: absolute sample indices [0, frame_spp)
@@ -331,7 +338,7 @@ def main():
 
     rays = sum(s["rays"] for s in stats)
     paths = sum(s["paths"] for s in stats)
-    mine = torch.tensor([float(rays), float(paths), dt, t_render, t_allreduce, float(my_e - my_b)], dtype=torch.float64, device=dev)
+    mine = torch.tensor([float(rays), float(paths), dt, t_render, t_allreduce, float(my_e - my_b)], dtype=torch.float64, device=coll_dev)
     if world > 1:
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
@@ -368,6 +375,8 @@ def main():
         "per_rank_mrays_s": {"min": min(per_rank_rate), "max": max(per_rank_rate)},
         "accum_checksum": checksum,
     }
+    if args.gloo_gpu:
+        out["gloo_gpu"] = "gloo collectives staged through host memory around the HIP renderer, ranks sharing GPUs: a functional run of the N-rank path, not a measurement"
     if rehearse:
         out["rehearsal"] = {"rank": rehearse[0], "world": rehearse[1],
                             "note": "ONE GPU rendering the share rank r of an N-rank run would render (same jobs, same sample indices); no collective ran"}

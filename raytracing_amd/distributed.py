@@ -32,9 +32,15 @@ def broadcast_blob(blob, device, src=0):
 
 
 def allreduce_accum(accum):
-    """Sum of the per-rank fp32 radiance accumulators (in place)."""
+    """Sum of the per-rank fp32 radiance accumulators (in place).  RCCL reduces device tensors directly; under gloo a device tensor
+    is staged through host memory (the functional N-rank run on a box with fewer GPUs than ranks)."""
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(accum, op=dist.ReduceOp.SUM)
+        if accum.is_cuda and dist.get_backend() == "gloo":
+            host = accum.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            accum.copy_(host)
+        else:
+            dist.all_reduce(accum, op=dist.ReduceOp.SUM)
     return accum
 
 
