@@ -414,11 +414,11 @@ def seeded_compare(args, local_rank, dev, rtd, accum, sync, spp_step):
 
 def report_kernels(args, R, accum, stats, jobs, rays):
     """rank 0, after the timed region: per-kernel times of the timed steps, the roofline of the dominant kernel (k_trace),
-    and two untimed extra renders -- one step on ONE lane (launch durations without the other lane's kernels sharing the
-    machine) and a 1-spp pass of the counting kernel (reference-order test counts: what the traversal replaces)."""
+    and two untimed extra renders -- one step on ONE lane with the shadow traversals on the same stream (launch durations without
+    another lane's or stream's kernels sharing the machine: the only figures that attribute time to a kernel) and a 1-spp pass of the counting kernel (reference-order test counts: what the traversal replaces)."""
     rt = R.rt
     b, e = jobs[0]
-    alone = R.render(accum, b, e, flags=rt.RENDER_ONE_LANE, samples_per_pass=stats[0]["samples_per_pass"] if stats else 0)
+    alone = R.render(accum, b, e, flags=rt.RENDER_ONE_LANE | rt.RENDER_SERIAL_SHADOW, samples_per_pass=stats[0]["samples_per_pass"] if stats else 0)
     # the waves' record steps come from a step of their own: the counter is one same-address atomic per wave (5 % of the frame), so neither the
     # timed steps nor the one-lane step above run with it
     stepped = R.render(accum, b, e, flags=rt.RENDER_COUNT_STEPS, samples_per_pass=stats[0]["samples_per_pass"] if stats else 0)

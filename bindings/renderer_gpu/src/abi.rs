@@ -41,6 +41,7 @@ pub const RT_RENDER_ONE_LANE: u32 = 4;
 pub const RT_RENDER_LANE_WALK: u32 = 8;
 pub const RT_RENDER_MATERIAL_BINS: u32 = 16;
 pub const RT_RENDER_COUNT_STEPS: u32 = 32;
+pub const RT_RENDER_SERIAL_SHADOW: u32 = 64;
 
 #[repr(C)]
 #[derive(Clone, Copy, Default)]

@@ -183,6 +183,8 @@ typedef struct rt_render_params {
                                         scattering kinds), -5 % on `earth`: k_shade is bound by its f64 path-state traffic, not by
                                         divergent material branches, so the default shades in queue order.  Ignored in scenes with
                                         one kind of scattering material. */
+#define RT_RENDER_SERIAL_SHADOW 64u /* trace the MIS shadow rays on the pass's own stream instead of a side stream beside the next bounce's path rays
+                                        (A-B and attribution: with everything on one stream a kernel's elapsed time is its own; same frame) */
 #define RT_RENDER_ONE_LANE 4u    /* run the passes of a call one after the other instead of two at a time (A-B; same frame) */
 
 typedef struct rt_stats {

@@ -16,7 +16,7 @@ from ._ffi import ASSETS, RenderParams, Stats
 INT_MIS, INT_LIGHT_IS, INT_BRDF, INT_UNIFORM = 0, 1, 2, 3
 INTEGRATORS = {"mis": INT_MIS, "light_is": INT_LIGHT_IS, "brdf": INT_BRDF, "uniform": INT_UNIFORM}
 NONE = 0xFFFFFFFF
-RENDER_COUNT_TESTS, RENDER_NO_SORT, RENDER_ONE_LANE, RENDER_LANE_WALK, RENDER_MATERIAL_BINS, RENDER_COUNT_STEPS = 1, 2, 4, 8, 16, 32
+RENDER_COUNT_TESTS, RENDER_NO_SORT, RENDER_ONE_LANE, RENDER_LANE_WALK, RENDER_MATERIAL_BINS, RENDER_COUNT_STEPS, RENDER_SERIAL_SHADOW = 1, 2, 4, 8, 16, 32, 64
 BVH_AXIS_MODES = {"seeded": 0, "min_area": 1}   # include/rt_host.h RTH_BVH_AXIS_*
 NOALLOC_MAX_RAYS = 262144
 PDF_COSINE, PDF_UNIFORM_HEMI, PDF_UNIFORM_SPHERE, PDF_FUZZY, PDF_DIELECTRIC, PDF_CONE = range(6)

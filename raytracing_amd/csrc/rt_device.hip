@@ -386,7 +386,7 @@ static int capture_queue(Workspace& ws, hipStream_t st, const uint32_t* queue, u
 
 static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bool explicit_lists, uint32_t width, uint32_t height, uint32_t sample0, int32_t max_depth,
                      int32_t integrator, uint64_t seed, bool count_tests, bool sort_rays, EventTimer& tm, uint64_t& launches, Capture* cap = nullptr,
-                     bool lane_walk = false, bool want_sig = false, bool bins = false, bool count_steps = false, uint64_t* tail_bounces = nullptr) {
+                     bool lane_walk = false, bool want_sig = false, bool bins = false, bool count_steps = false, uint64_t* tail_bounces = nullptr, bool serial_shadow = false) {
     PathBuffers pbk = ws.pb;   // what the kernels see: signatures only for rt_sample_radiance_sig
     if (!want_sig) pbk.sig = nullptr;
     else HIP_OK(hipMemsetAsync(pbk.sig, 0, (size_t)n * sizeof(unsigned long long), st));
@@ -423,7 +423,7 @@ static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bo
     // nodes walk a few dozen records per ray (random spheres: 900 k unsorted rays in 0.15-0.4 ms against 0.4 ms for the two sorts alone)
     static const int small_tuned = tune("RT_TUNE_SMALL_QUEUE", 0);
     const uint32_t small_queue = small_tuned > 0 ? (uint32_t)small_tuned : sc->hdr.n_nodes <= 4096u ? RT_SMALL_QUEUE_TINY_SCENE : RT_SMALL_QUEUE;
-    const bool side = side_on && cap == nullptr && !use_walk && !count_tests;
+    const bool side = side_on && !serial_shadow && cap == nullptr && !use_walk && !count_tests;
     bool shadow_pending = false;
     for (int32_t bounce = 0; bounce < max_depth && live > 0; ++bounce) {
         const int nxt = cur ^ 1;
@@ -1295,7 +1295,7 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
             const uint32_t s0 = p->spp_begin + k * spass;
             const uint32_t ns = std::min(spass, p->spp_end - s0);
             int r = run_paths(sc, ws, L.st, npix * ns, false, p->width, p->height, s0, p->max_depth, p->integrator, p->seed, count_tests, sort_rays, L.tm, L.launches, nullptr, (p->flags & RT_RENDER_LANE_WALK) != 0, false,
-                              (p->flags & RT_RENDER_MATERIAL_BINS) != 0, (p->flags & (RT_RENDER_COUNT_STEPS | RT_RENDER_COUNT_TESTS)) != 0, &L.tail_bounces);
+                              (p->flags & RT_RENDER_MATERIAL_BINS) != 0, (p->flags & (RT_RENDER_COUNT_STEPS | RT_RENDER_COUNT_TESTS)) != 0, &L.tail_bounces, (p->flags & RT_RENDER_SERIAL_SHADOW) != 0);
             if (r != RT_OK) return r;
             if (k > 0) {
                 std::unique_lock<std::mutex> lk(mu);
@@ -1385,7 +1385,7 @@ static void job_main(rt_job* J) {
         for (uint32_t s0 = p.spp_begin; s0 < p.spp_end; s0 += J->spass) {
             const uint32_t ns = std::min(J->spass, p.spp_end - s0);
             int r = run_paths(sc, ws, st, npix * ns, false, p.width, p.height, s0, p.max_depth, p.integrator, p.seed, false, sort_rays, tm, launches, nullptr,
-                              (p.flags & RT_RENDER_LANE_WALK) != 0, false, (p.flags & RT_RENDER_MATERIAL_BINS) != 0, (p.flags & (RT_RENDER_COUNT_STEPS | RT_RENDER_COUNT_TESTS)) != 0, &tail_bounces);
+                              (p.flags & RT_RENDER_LANE_WALK) != 0, false, (p.flags & RT_RENDER_MATERIAL_BINS) != 0, (p.flags & (RT_RENDER_COUNT_STEPS | RT_RENDER_COUNT_TESTS)) != 0, &tail_bounces, (p.flags & RT_RENDER_SERIAL_SHADOW) != 0);
             if (r != RT_OK) return r;
             if (!waited) {   // the job begun before this one adds its sums first (fixed order of the fp32 additions)
                 std::unique_lock<std::mutex> lk(sc->job_mu);

@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _latest():
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_bench.json")))
+    # rNNx_bench.json is a headline line; rNNx_<workload>_bench.json (the other BASELINE configs, tools/measure_configs.sh) is not
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_bench.json")) if re.fullmatch(r"r\d+[a-z]*_bench\.json", os.path.basename(f)))
     assert files, "no committed bench line"
     return files[-1]
 
@@ -88,3 +89,24 @@ def test_kernel_trace_summary_beside_it_names_the_roofline_kernel():
     # the counting step's launches run like the timed ones (two lanes inside the call), a few percent slower for their counter: priced at the timed average
     shared_avg = (total_ms - per_step * r["one_lane"]["avg_launch_ms"] - (extra - per_step) * r["avg_launch_ms"]) / (calls - extra)
     assert abs(shared_avg - r["avg_launch_ms"]) < 0.1 * r["avg_launch_ms"], (shared_avg, r["avg_launch_ms"])
+
+
+def test_every_other_baseline_config_has_a_tracked_line_and_kernel_stats():
+    # configs[0], [1], [3], [4] (both scenes of [4]) measured where the driver can see it -- the line `python bench.py --workload X`
+    # printed and the `rocprofv3 --kernel-trace --stats` summary of the same command, under profiles/ (tools/measure_configs.sh)
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    for wl in sorted(set(bench.WORKLOADS) - {"pagoda_1080p_mis"}):
+        lines = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]*_{wl}_bench.json")))
+        assert lines, wl
+        d = _line(lines[-1])
+        scene, _, w, h, integ, depth = bench.WORKLOADS[wl]
+        c = d["config"]
+        assert (c["workload"], c["scene"], c["width"], c["height"], c["max_depth"]) == (wl, scene, w, h, depth) and c["integrator"] == bench.INTEGRATOR_NAMES[integ]
+        assert d["n_gpus"] == 1 and d["value"] > 0 and d["paths"] == w * h * c["spp_total"]
+        assert 0 < d["roofline"]["frac"] <= 1 and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["single_thread"]["value"] > 0
+        stats = lines[-1].replace("_bench.json", "_kernel_stats.csv")
+        assert os.path.exists(stats), stats
+        rows = list(csv.DictReader(open(stats)))
+        assert any(r["Name"].startswith("void k_trace<false") and int(r["Calls"]) > 0 for r in rows), wl

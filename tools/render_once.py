@@ -12,5 +12,5 @@ spass = int(sys.argv[5]) if len(sys.argv) > 5 else spp
 W, H = (int(os.environ.get("RT_W", "1920")), int(os.environ.get("RT_H", "1080")))
 ctx = rt.Context(0); gs = ctx.upload(rt.HostScene.builtin(name, bvh_seed=3, bvh_axis=os.environ.get("RT_BVH_AXIS", "min_area")))
 acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda"); torch.cuda.synchronize()
-st = gs.render(acc.data_ptr(), W, H, 0, spp, depth, integ, samples_per_pass=spass).as_dict()
+st = gs.render(acc.data_ptr(), W, H, 0, spp, depth, integ, samples_per_pass=spass, flags=int(os.environ.get("RT_RENDER_FLAGS", str(rt.RENDER_SERIAL_SHADOW)))).as_dict()   # one stream: a kernel's elapsed time is its own
 print(st)
