@@ -301,6 +301,16 @@ static void launch_trace(rt_scene* sc, unsigned long long* lstats, uint32_t lcap
     unsigned long long d0[16];
     (void)hipMemcpyAsync(d0, lstats, sizeof d0, hipMemcpyDeviceToHost, st);
     (void)hipStreamSynchronize(st);
+    static uint4* dlog = nullptr; static unsigned int dlog_cap = 0; static int dlog_launch = 0;
+    const char* dlog_dir = getenv("RT_DIAG_LOG");
+    if (dlog_dir && *dlog_dir && !count) {
+        if (!dlog) { dlog_cap = 6u << 20; if (hipMalloc((void**)&dlog, (size_t)dlog_cap * sizeof(uint4)) != hipSuccess) { dlog = nullptr; dlog_cap = 0; } }
+        const unsigned int zero = 0, every = (unsigned int)std::max(tune("RT_DIAG_LOG_EVERY", 400), 1);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dlog), &dlog, sizeof dlog); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dlog_n), &zero, sizeof zero);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dlog_cap), &dlog_cap, sizeof dlog_cap); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dlog_every), &every, sizeof every);
+        const unsigned int group = (unsigned int)std::max(tune("RT_DIAG_LOG_GROUP", 64), 1);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dlog_group), &group, sizeof group);
+    }
 #endif
     if (count) { if (inst) RT_LAUNCH_TRACE(true, true); else RT_LAUNCH_TRACE(true, false); }
     else { if (inst) RT_LAUNCH_TRACE(false, true); else RT_LAUNCH_TRACE(false, false); }
@@ -314,6 +324,15 @@ static void launch_trace(rt_scene* sc, unsigned long long* lstats, uint32_t lcap
         (void)hipStreamSynchronize(st);
         for (int k = 0; k < 16; ++k) if (k != 10) d[k] -= d0[k];
         (void)hipMemsetAsync(lstats + 10, 0, sizeof(unsigned long long), st);
+        if (dlog_dir && *dlog_dir && !count && dlog) {   // the sampled waves' step log of this launch -> <dir>/launch_NNN_{p|s}.bin (tools/lane_log.py)
+            unsigned int nlog = 0;
+            (void)hipMemcpyFromSymbol(&nlog, HIP_SYMBOL(g_dlog_n), sizeof nlog);
+            nlog = std::min(nlog, dlog_cap);
+            std::vector<uint4> hl(nlog);
+            if (nlog) (void)hipMemcpy(hl.data(), dlog, (size_t)nlog * sizeof(uint4), hipMemcpyDeviceToHost);
+            char fn[512]; snprintf(fn, sizeof fn, "%s/launch_%03d_%c_%llu.bin", dlog_dir, dlog_launch++, shadow ? 's' : 'p', d[0]);
+            if (FILE* f = fopen(fn, "wb")) { if (nlog) fwrite(hl.data(), sizeof(uint4), nlog, f); fclose(f); }
+        }
         const double w = (double)std::max(d[8], 1ull);
         fprintf(stderr, "[diag] rays %llu waves %llu  steps/wave %.0f  leaf steps/wave %.0f  lane use %.1f%%  cycles/wave %.0f  cycles/step %.0f  wait/step %.0f  max steps %llu  exact box steps/wave %.1f  exact tri steps/wave %.1f  | of a wave's cycles: set-up %.1f%%  leaf steps %.1f%% (exact tri blocks %.1f%%)  exact box blocks %.1f%%  scalar-load wait %.1f%%\n",
                 d[0], d[8], d[4] / w, d[5] / w, 100.0 * d[9] / (64.0 * std::max(d[4], 1ull)), d[7] / w, (double)d[7] / std::max(d[4], 1ull), (double)d[6] / std::max(d[4], 1ull), d[10], d[11] / w, d[12] / w,

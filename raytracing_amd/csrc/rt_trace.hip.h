@@ -30,8 +30,21 @@ struct LaneCount {
 #ifdef RT_TRACE_DIAG  // diagnostic build only (make diag): wave-level step counts and s_memtime cycle stamps
     uint64_t steps, leaf_steps, cyc_wait, cyc_total, lane_steps, exact_box, exact_tri, cyc_xbox, cyc_xtri, cyc_setup, cyc_leaf, leaf_open;
     uint32_t diag_flags;  // bit 0: top-level walk in the NaN-capable (literal) mode, bit 1: ray not certified for pruning, bit 2: fp32 range guard failed
+    uint32_t dlog_wave;   // wave index if this wave's steps are logged (diag_log), else 0xFFFFFFFF
 #endif
 };
+#ifdef RT_TRACE_DIAG
+// Step log of sampled waves (diagnostic build, RT_DIAG_LOG=<dir>): one entry per record step = { wave, stream offset, mask of the lanes that take
+// part }.  A ray's visited records do not depend on its wave-mates, so the log gives every sampled ray's exact visited set and any regrouping
+// of those rays can be costed offline (tools/lane_log.py): the union of the visited offsets of a group is the step count of a wave made of it.
+__device__ uint4* g_dlog; __device__ unsigned int g_dlog_n, g_dlog_cap, g_dlog_every, g_dlog_group;
+RT_DEV void diag_log(uint32_t wave, uint32_t off, uint64_t m) {
+    if (wave != 0xFFFFFFFFu && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) {
+        const unsigned int i = atomicAdd(&g_dlog_n, 1u);
+        if (i < g_dlog_cap) g_dlog[i] = make_uint4(wave, off, (uint32_t)m, (uint32_t)(m >> 32));
+    }
+}
+#endif
 
 struct GeomS { double d[9]; uint32_t kind, xform; };
 RT_DEV GeomS load_geom(cptr<rt_geom> geom, uint32_t p) {
@@ -789,6 +802,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
             if (cnt.cyc_setup == 0) cnt.cyc_setup = c0 - cnt.cyc_total;   // kernel entry (cyc_total holds the start stamp) to the first record
             if (cnt.leaf_open) cnt.cyc_leaf += c0 - cnt.leaf_open;
             cnt.leaf_open = (rec & RT_STREAM_KIND) ? c0 : 0;
+            if (LEVEL == 0) diag_log(cnt.dlog_wave, off | ((rec & RT_STREAM_KIND) >> 2), mask_reached(off, wait));   // records are 16-byte aligned: the kind rides in the low bits
 #endif
             // "a TRI2 leaf in the space the rays are in" as ONE integer test (made opaque to the optimiser, which would otherwise turn it back into
             // two booleans and combine those as 64-bit lane masks: 10 scalar instructions instead of 5 on every step)
@@ -824,6 +838,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
                 if ((rec2 & RT_STREAM_KIND) == RT_STREAM_INNER) {
 #ifdef RT_TRACE_DIAG
                     cnt.steps += 1;
+                    if (LEVEL == 0) diag_log(cnt.dlog_wave, off | ((rec & RT_STREAM_KIND) >> 2), mask_reached(off, wait));   // records are 16-byte aligned: the kind rides in the low bits
 #endif
                     cnt.wsteps += 1u;
                     m_pass = box_step<16, MODE, COUNT>(w, bf, ps, 0u, off, wait, rec2, nodes, src, h, t_min, cnt);
@@ -990,6 +1005,7 @@ __global__ __launch_bounds__(RT_TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(
     LaneCount cnt; cnt.box = cnt.tri = cnt.sph = cnt.bad = 0; cnt.pruned_until = 0; cnt.uncertified = 0; cnt.wsteps = 0;
 #ifdef RT_TRACE_DIAG
     cnt.steps = cnt.leaf_steps = cnt.cyc_wait = cnt.lane_steps = cnt.exact_box = cnt.exact_tri = 0; cnt.cyc_xbox = cnt.cyc_xtri = cnt.cyc_setup = cnt.cyc_leaf = cnt.leaf_open = 0; cnt.cyc_total = __builtin_readcyclecounter(); cnt.diag_flags = 0;
+    cnt.dlog_wave = (g_dlog != nullptr && !COUNT && ((tid >> 6) / g_dlog_group % g_dlog_every) == 0u) ? (tid >> 6) : 0xFFFFFFFFu;   // groups of consecutive waves
 #endif
     if (REGS) {
         LaneHitRegs hr; hr.best = t_max; hr.prim = RT_NONE; hr.inst = RT_NONE;
