@@ -310,7 +310,7 @@ RT_DEV bool strict_filter_init(StrictFilter& f, d3 o, d3 d, const SceneDev& sc) 
     return ok;
 }
 template <int B>  // B: first dword of the record's LOCAL box inside the window; returns the lanes whose line misses it
-RT_DEV lanemask strict_filter(const StrictFilter& f, const Window& w) {
+RT_DEV lanemask strict_filter(const StrictFilter& f, const Window& w, float dis) {   // dis: PruneState::dis
     f2 nx, ny, nz, fx, fy, fz;
     PK_FMA_BB(nx, wpair<B + 0>(w), f.inv_xy, 0, f.invz_cnx, 1);
     PK_FMA_BB(ny, wpair<B + 2>(w), f.inv_xy, 1, f.cn_yz, 0);
@@ -325,10 +325,11 @@ RT_DEV lanemask strict_filter(const StrictFilter& f, const Window& w) {
         "v_min_f32 %[n2], %[nza], %[nzb]\n\tv_max_f32 %[f2], %[fza], %[fzb]\n\t"
         "v_max3_f32 %[n0], %[n0], %[n1], %[n2]\n\t"
         "v_min3_f32 %[f0], %[f0], %[f1], %[f2]\n\t"
+        "v_max_f32 %[f0], %[f0], %[dis]\n\t"       // a lane that may not prune: far = +inf, never "near > far"
         "v_cmp_gt_f32_e64 %[m], %[n0], %[f0]"
         : [n0] "=&v"(n0), [n1] "=&v"(n1), [n2] "=&v"(n2), [f0] "=&v"(f0), [f1] "=&v"(f1), [f2] "=&v"(f2v), [m] "=&s"(m)
         : [nxa] "v"(nx.x), [nxb] "v"(nx.y), [nya] "v"(ny.x), [nyb] "v"(ny.y), [nza] "v"(nz.x), [nzb] "v"(nz.y),
-          [fxa] "v"(fx.x), [fxb] "v"(fx.y), [fya] "v"(fy.x), [fyb] "v"(fy.y), [fza] "v"(fz.x), [fzb] "v"(fz.y));
+          [fxa] "v"(fx.x), [fxb] "v"(fx.y), [fya] "v"(fy.x), [fyb] "v"(fy.y), [fza] "v"(fz.x), [fzb] "v"(fz.y), [dis] "v"(dis));
     return m;
 }
 // Is the direction (in the pruned space) at least 2^-24 |d|_inf away from perpendicular to every triangle normal of that
@@ -412,7 +413,10 @@ struct PruneState {
     StrictFilter sf;
     lanemask enable;
     uint32_t s0, s1, s2;
-    bool any_suspect;  // wave-uniform
+    uint32_t any_suspect;  // wave-uniform, one SGPR (a bool becomes a 64-bit lane mask)
+    float dis;         // per lane: -inf if the lane may prune (a bit of `enable`), +inf if not.  The strict filter takes max(far, dis) before its last compare, so a
+                       // lane that may not prune never reports "near > far": one VALU instruction instead of `& enable`, whose SGPR pair the allocator kept
+                       // spilled (two v_readlane per inner step): 2 238 -> 2 277 Mrays/s, frames bit-identical (profiles/r03m_ab_spills.txt)
     uint32_t none;     // wave-uniform: 1 iff enable == 0 (kept as an integer: the hot loop tests it together with the record kind)
 };
 RT_DEV lanemask mask_lt_u32(uint32_t v, uint32_t s) { lanemask m; asm("v_cmp_lt_u32_e64 %0, %1, %2" : "=s"(m) : "v"(v), "s"(s)); return m; }
@@ -628,7 +632,7 @@ RT_DEV lanemask box_step(const Window& w, const BoxFilter& bf, const PruneState&
         no_strict_test = (uint32_t)__builtin_amdgcn_readfirstlane((int)no_strict_test);
         asm("" : "+s"(no_strict_test));
         if (no_strict_test == 0u) {
-            sp = strict_filter<B + 8>(ps.sf, w) & ps.enable;
+            sp = strict_filter<B + 8>(ps.sf, w, ps.dis);
             if (ps.any_suspect) {  // a subtree that holds one of the ray's suspect leaves is not pruned
                 const uint32_t span = wword<B + 6>(w) - off;
                 sp &= ~(mask_lt_u32(ps.s0 - off, span) | mask_lt_u32(ps.s1 - off, span) | mask_lt_u32(ps.s2 - off, span));
@@ -742,7 +746,7 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
     uint32_t off = scalar_u32(first), cur_xf = prune ? sc.prune_xf : RT_NONE;
     lanemask clean = 0ull;
     PruneState ps;
-    ps.enable = 0ull; ps.none = 1u; ps.s0 = ps.s1 = ps.s2 = 0xFFFFFFFFu; ps.any_suspect = false;
+    ps.enable = 0ull; ps.none = 1u; ps.s0 = ps.s1 = ps.s2 = 0xFFFFFFFFu; ps.any_suspect = 0; ps.dis = __builtin_inff();
     if (prune) {
         const RayS ray = src.get();
         d3 xo, xd;
@@ -756,7 +760,8 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
 #endif
         clean = __builtin_amdgcn_ballot_w64(c);
         ps.s0 = sus.leaf[0]; ps.s1 = sus.leaf[1]; ps.s2 = sus.leaf[2];
-        ps.any_suspect = __builtin_amdgcn_ballot_w64(c && sus.leaf[0] != 0xFFFFFFFFu) != 0ull;
+        ps.any_suspect = (uint32_t)__builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(c && sus.leaf[0] != 0xFFFFFFFFu) != 0ull ? 1 : 0);
+        asm("" : "+s"(ps.any_suspect));
         RT_RECONVERGE();
     }
     const uint64_t base = (uint64_t)(full ? sc.stream_full : sc.stream);
@@ -778,11 +783,13 @@ RT_DEV void traverse_impl(const SceneDev& sc, uint32_t first, const RAYSRC& src,
             if (prune && cur_xf == sc.prune_xf) {  // inner records carry boxes of THIS space only
                 const bool ok = strict_filter_init(ps.sf, xo, xd, sc);
                 ps.enable = clean & __builtin_amdgcn_ballot_w64(ok); ps.none = (uint32_t)__builtin_amdgcn_readfirstlane(ps.enable == 0ull ? 1 : 0);
+                ps.dis = mask_lane(ps.enable) ? -__builtin_inff() : __builtin_inff();
 #ifdef RT_TRACE_DIAG
                 cnt.diag_flags |= (active && !ok) ? 4u : 0u;
 #endif
             } else {
                 ps.sf.inv_xy = ps.sf.invz_cnx = ps.sf.cn_yz = ps.sf.cp_xy = ps.sf.cpz_ = (f2){0.f, 0.f};
+                ps.dis = __builtin_inff();
             }
         }
         uint32_t want = cur_xf;
