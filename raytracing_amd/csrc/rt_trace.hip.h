@@ -629,8 +629,10 @@ RT_DEV lanemask box_step(const Window& w, const BoxFilter& bf, const PruneState&
         // (a subtree that is never pruned carries the local box (-inf, +inf): near = -inf, far = +inf for every enabled lane -- their fp32 1/d is finite
         // and non-zero -- so the filter itself answers "not pruned"; testing for it here would cost every step two scalar instructions)
         uint32_t no_strict_test = not_strict | ps.none;
-        no_strict_test = (uint32_t)__builtin_amdgcn_readfirstlane((int)no_strict_test);
-        asm("" : "+s"(no_strict_test));
+        if (!(__builtin_constant_p(not_strict) && not_strict != 0u)) {   // (the leaf-first call passes the constant 1: nothing to test, nothing to hide from the optimiser)
+            no_strict_test = (uint32_t)__builtin_amdgcn_readfirstlane((int)no_strict_test);
+            asm("" : "+s"(no_strict_test));
+        }
         if (no_strict_test == 0u) {
             sp = strict_filter<B + 8>(ps.sf, w, ps.dis);
             if (ps.any_suspect) {  // a subtree that holds one of the ray's suspect leaves is not pruned
