@@ -495,8 +495,18 @@ static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bo
         const dim3 sgrid((live + RT_SHADE_BLOCK * RT_SHADE_TILES - 1u) / (RT_SHADE_BLOCK * RT_SHADE_TILES));
 #define RT_LAUNCH_SHADE(KERNEL, NQ, NK, SQ, SK) hipLaunchKernelGGL(KERNEL, sgrid, dim3(RT_SHADE_BLOCK), 0, st, sc->dev, pbk, ws.queue[cur], order, c_in, (uint32_t)bounce, max_depth, integrator, \
                                                                    seed, NQ, NK, c_next, SQ, SK, c_shadow)
-        if (sorted) { if (compact) RT_LAUNCH_SHADE(k_shade<true>, ws.raw_queue, ws.raw_keys, ws.raw_squeue, ws.raw_skeys); else RT_LAUNCH_SHADE(k_shade<false>, ws.raw_queue, ws.raw_keys, ws.raw_squeue, ws.raw_skeys); }
-        else { if (compact) RT_LAUNCH_SHADE(k_shade_dense<true>, ws.queue[nxt], (uint32_t*)nullptr, ws.shadow_queue, (uint32_t*)nullptr); else RT_LAUNCH_SHADE(k_shade_dense<false>, ws.queue[nxt], (uint32_t*)nullptr, ws.shadow_queue, (uint32_t*)nullptr); }
+        // one build of the body per integrator (and record form): the MIS arm's light sample is dead weight in the three others
+#define RT_SHADE_SORTED(C, I) RT_LAUNCH_SHADE((k_shade<C, I>), ws.raw_queue, ws.raw_keys, ws.raw_squeue, ws.raw_skeys)
+#define RT_SHADE_DENSE(C, I) RT_LAUNCH_SHADE((k_shade_dense<C, I>), ws.queue[nxt], (uint32_t*)nullptr, ws.shadow_queue, (uint32_t*)nullptr)
+#define RT_SHADE_PICK(WHICH) do { \
+            if (integrator == RT_INT_MIS) { if (compact) WHICH(true, RT_INT_MIS); else WHICH(false, RT_INT_MIS); } \
+            else if (integrator == RT_INT_LIGHT_IS) WHICH(true, RT_INT_LIGHT_IS); \
+            else if (integrator == RT_INT_BRDF) WHICH(true, RT_INT_BRDF); \
+            else WHICH(true, RT_INT_UNIFORM); } while (0)
+        if (sorted) RT_SHADE_PICK(RT_SHADE_SORTED); else RT_SHADE_PICK(RT_SHADE_DENSE);
+#undef RT_SHADE_PICK
+#undef RT_SHADE_DENSE
+#undef RT_SHADE_SORTED
 #undef RT_LAUNCH_SHADE
         uint32_t next_live = live, shadow_live = live;   // small queues: bounds
         if (small) {

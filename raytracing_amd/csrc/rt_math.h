@@ -53,11 +53,21 @@ RT_DEV d3 mat_t_mul_xyz0(const double* m, d3 v) {
 }
 
 // ---- Philox4x32-10, counter = (pixel, sample, level, block), key = seed ------------------------
+RT_DEV void mul_wide_u32(uint32_t k, uint32_t c, uint32_t& hi, uint32_t& lo) {
+#ifdef RT_PHILOX_SPLIT_MUL
+    hi = __umulhi(k, c); lo = k * c;
+#else
+    unsigned long long p, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=&v"(p), "=s"(carry) : "s"(k), "v"(c));
+    hi = (uint32_t)(p >> 32); lo = (uint32_t)p;
+#endif
+}
 RT_DEV void philox4x32_10(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t hi0, lo0, hi1, lo1;   // both halves of a product from ONE v_mad_u64_u32 (left to itself the compiler issues v_mul_hi_u32 + v_mul_lo_u32, each as slow)
+        mul_wide_u32(0xD2511F53u, c0, hi0, lo0);
+        mul_wide_u32(0xCD9E8D57u, c2, hi1, lo1);
         uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -107,7 +117,9 @@ RT_DEV d3 rand_in_unit_sphere(Rng& rng) {  // math.rs:12-19 (rejection; each lan
     for (;;) {
         double a = rng.range(-1.0, 1.0), b = rng.range(-1.0, 1.0), c = rng.range(-1.0, 1.0);
         d3 p = mk(a, b, c);
-        if (length(p) < 1.0) return p;
+        // length(p) < 1.0 (math.rs:16), decided without the square root: sqrt is monotone and correctly rounded, sqrt(1 - 2^-53) rounds to
+        // 1 - 2^-53 and sqrt(1) = 1, so RN(sqrt(s)) < 1 <=> s < 1 for the same rounded s = (a a + b b) + c c (NaN: false both ways)
+        if (dot(p, p) < 1.0) return p;
     }
 }
 RT_DEV d3 rand_cosine_hemisphere(Rng& rng) {  // math.rs:25-36

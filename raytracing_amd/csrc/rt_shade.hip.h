@@ -225,11 +225,14 @@ __global__ __launch_bounds__(256) void k_bin_scatter(const uint8_t* __restrict__
                         uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_keys, uint32_t* __restrict__ next_count,                                    \
                         uint32_t* __restrict__ shadow_queue, uint32_t* __restrict__ shadow_keys, uint32_t* __restrict__ shadow_count
 #define RT_SHADE_ARGS sc, pb, queue, order, n_ptr, bounce, max_depth, integrator, seed, next_queue, next_keys, next_count, shadow_queue, shadow_keys, shadow_count
-template <bool COMPACT>
+// INTEG: the integrator as a compile-time constant (-1: the run-time argument).  The body is one function for four integrators; built per integrator the
+// dead arms go (the light sample and its 30-odd live doubles exist in the MIS build only) and the allocator has that much less to keep.
+template <bool COMPACT, int INTEG>
 RT_DEV void shade_block(const SceneDev& sc, const PathBuffers& pb, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ order, const uint32_t* __restrict__ n_ptr,
-                        uint32_t bounce, int32_t max_depth, int32_t integrator, uint64_t seed,
+                        uint32_t bounce, int32_t max_depth, int32_t integrator_arg, uint64_t seed,
                         uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_keys, uint32_t* __restrict__ next_count,
                         uint32_t* __restrict__ shadow_queue, uint32_t* __restrict__ shadow_keys, uint32_t* __restrict__ shadow_count) {
+    const int32_t integrator = INTEG >= 0 ? INTEG : integrator_arg;
     const uint32_t n = *n_ptr;
     // A block shades RT_SHADE_TILES tiles of 256 queue slots one after the other and parks what each thread wants to push in LDS; the
     // queues are then extended with ONE atomic per block and queue (push_tiles_block).  Whole blocks leave together: every wave of a
@@ -432,8 +435,11 @@ RT_DEV void shade_block(const SceneDev& sc, const PathBuffers& pb, const uint32_
 // issue slots, where a faster k_shade only hands its time to the k_trace of the other lane.  k_shade_dense: 4 waves per SIMD (128 VGPRs + 88 B of
 // scratch), a third faster on its own -- for the small scenes (no ray sorting: earth, broken cube), where shading is the larger half of the frame:
 // +4 % there, -2 % on the pagoda.
-template <bool COMPACT> __global__ __launch_bounds__(RT_SHADE_BLOCK) RT_SHADE_OCCUPANCY void k_shade(RT_SHADE_PARAMS) { shade_block<COMPACT>(RT_SHADE_ARGS); }
-template <bool COMPACT> __global__ __launch_bounds__(RT_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_shade_dense(RT_SHADE_PARAMS) { shade_block<COMPACT>(RT_SHADE_ARGS); }
+template <bool COMPACT, int INTEG = -1> __global__ __launch_bounds__(RT_SHADE_BLOCK) RT_SHADE_OCCUPANCY void k_shade(RT_SHADE_PARAMS) { shade_block<COMPACT, INTEG>(RT_SHADE_ARGS); }
+#ifndef RT_SHADE_DENSE_WAVES
+#define RT_SHADE_DENSE_WAVES 4
+#endif
+template <bool COMPACT, int INTEG = -1> __global__ __launch_bounds__(RT_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_SHADE_DENSE_WAVES, RT_SHADE_DENSE_WAVES))) void k_shade_dense(RT_SHADE_PARAMS) { shade_block<COMPACT, INTEG>(RT_SHADE_ARGS); }
 
 // ------------------------------------------------------------------------------------------------
 // k_unwind / k_accumulate / k_resolve
