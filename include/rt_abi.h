@@ -170,7 +170,7 @@ typedef struct rt_render_params {
     uint32_t flags;              /* RT_RENDER_* */
 } rt_render_params;
 #define RT_RENDER_COUNT_TESTS 1u /* also count box/primitive tests (slower kernel variant) */
-#define RT_RENDER_NO_SORT 2u     /* do not sort the ray queues by coherence key (octant | origin cell | direction bin); debug / A-B */
+#define RT_RENDER_NO_SORT 2u     /* do not sort the ray queues by coherence key (octant | origin cell | direction bin | foot point of the line); debug / A-B */
 #define RT_RENDER_LANE_WALK 8u   /* A-B: trace secondary and shadow rays with the per-lane walk (k_walk: own cursor and vector loads per lane, finished
                                   * lanes take the next ray) in scenes that qualify (a pruned space, no instances); same frame, measured slower than the
                                   * default wave-coherent walk */

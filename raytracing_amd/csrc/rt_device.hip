@@ -310,6 +310,10 @@ static void launch_trace(rt_scene* sc, unsigned long long* lstats, uint32_t lcap
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dlog_cap), &dlog_cap, sizeof dlog_cap); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dlog_every), &every, sizeof every);
         const unsigned int group = (unsigned int)std::max(tune("RT_DIAG_LOG_GROUP", 64), 1);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dlog_group), &group, sizeof group);
+        static float* dray = nullptr; static unsigned int dray_cap = 0;
+        if (!dray) { dray_cap = 2u << 20; if (hipMalloc((void**)&dray, (size_t)dray_cap * 8u * sizeof(float)) != hipSuccess) { dray = nullptr; dray_cap = 0; } }
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dray), &dray, sizeof dray); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dray_n), &zero, sizeof zero);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dray_cap), &dray_cap, sizeof dray_cap);
     }
 #endif
     if (count) { if (inst) RT_LAUNCH_TRACE(true, true); else RT_LAUNCH_TRACE(true, false); }
@@ -332,6 +336,16 @@ static void launch_trace(rt_scene* sc, unsigned long long* lstats, uint32_t lcap
             if (nlog) (void)hipMemcpy(hl.data(), dlog, (size_t)nlog * sizeof(uint4), hipMemcpyDeviceToHost);
             char fn[512]; snprintf(fn, sizeof fn, "%s/launch_%03d_%c_%llu.bin", dlog_dir, dlog_launch++, shadow ? 's' : 'p', d[0]);
             if (FILE* f = fopen(fn, "wb")) { if (nlog) fwrite(hl.data(), sizeof(uint4), nlog, f); fclose(f); }
+            unsigned int nray = 0, ray_cap = 0; float* dray_p = nullptr;
+            (void)hipMemcpyFromSymbol(&nray, HIP_SYMBOL(g_dray_n), sizeof nray); (void)hipMemcpyFromSymbol(&ray_cap, HIP_SYMBOL(g_dray_cap), sizeof ray_cap);
+            (void)hipMemcpyFromSymbol(&dray_p, HIP_SYMBOL(g_dray), sizeof dray_p);
+            nray = std::min(nray, ray_cap);
+            if (dray_p && nray) {   // the same waves' rays -> <dir>/rays_NNN_{p|s}_<rays>.bin
+                std::vector<float> hr((size_t)nray * 8u);
+                (void)hipMemcpy(hr.data(), dray_p, hr.size() * sizeof(float), hipMemcpyDeviceToHost);
+                snprintf(fn, sizeof fn, "%s/rays_%03d_%c_%llu.bin", dlog_dir, dlog_launch - 1, shadow ? 's' : 'p', d[0]);
+                if (FILE* f = fopen(fn, "wb")) { fwrite(hr.data(), sizeof(float), hr.size(), f); fclose(f); }
+            }
         }
         const double w = (double)std::max(d[8], 1ull);
         fprintf(stderr, "[diag] rays %llu waves %llu  steps/wave %.0f  leaf steps/wave %.0f  lane use %.1f%%  cycles/wave %.0f  cycles/step %.0f  wait/step %.0f  max steps %llu  exact box steps/wave %.1f  exact tri steps/wave %.1f  | of a wave's cycles: set-up %.1f%%  leaf steps %.1f%% (exact tri blocks %.1f%%)  exact box blocks %.1f%%  scalar-load wait %.1f%%\n",
@@ -1079,6 +1093,9 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
             v.sort_min[k] = (float)(mean - 0.5 * ext);
             v.sort_scale[k] = (float)(32.0 / ext);
         }
+#ifdef RT_TRACE_DIAG
+        fprintf(stderr, "[diag-sortgrid] %.9g %.9g %.9g %.9g %.9g %.9g\n", v.sort_min[0], v.sort_min[1], v.sort_min[2], v.sort_scale[0], v.sort_scale[1], v.sort_scale[2]);
+#endif
     }
     *out = sc;
     return RT_OK;

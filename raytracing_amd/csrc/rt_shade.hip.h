@@ -65,40 +65,68 @@ struct PathBuffers {
     uint32_t cap;
 };
 
-// Coherence key of a secondary ray: direction octant (3 bits) | Morton code of the origin cell
-// (5 bits per axis over the scene box).  The reference's per-axis slab test makes the visited node
-// set a function of "which boxes lie ahead of the origin on each axis", i.e. of octant and origin:
-// rays with equal keys walk nearly the same nodes, so a wave of them wastes few lanes.
-RT_DEV uint32_t spread5(uint32_t v) { v &= 31u; v = (v | (v << 8)) & 0x100Fu; v = (v | (v << 4)) & 0x10C3u; v = (v | (v << 2)) & 0x1249u; return v; }
+// Coherence key of a secondary ray.  A wave walks the UNION of its rays' records, so neighbours in the sorted queue should visit the same ones.
+// What a ray visits is decided by two tests: the reference's weak per-axis box test -- a function of "which boxes lie ahead of the origin on each
+// axis", i.e. of direction octant and ORIGIN -- and strict pruning, which is a function of the ray's LINE alone (a subtree is walked iff the line
+// passes its box, rt_trace.hip.h): two rays on nearly the same line share their deep records however far apart their origins lie along it.  Key:
+//     octant (3) | origin cell, Morton, RT_KEY_CELL bits per axis | direction bin, RT_KEY_DIR bits per axis of |d| / max|d| | foot point, 2 x RT_KEY_FOOT bits
+// where the foot point is the line's point closest to the centre of the sort grid, taken in the two axes other than the dominant direction axis
+// (which the direction bins imply) and Morton-interleaved.  Default 4 / 2 / 5 = 31 bits, four 8-bit radix passes.
+// r03q: the diagnostic build's step log gives every sampled ray's exact visited set, tools/key_eval.py costs any order of those
+// rays offline; it predicted 0.51 x the record steps of the first MIS shadow launch and 0.80 x of the first bounce for this layout against
+// octant | cell 4 | direction 3 (24 bits, r01-r03p), and the GPU agreed: 2 289 -> 2 608 Mrays/s on the headline, frames bit-identical (a path's radiance
+// does not depend on its place in a queue).  Measured beside it: 4/1/6 2 596, 4/1/5 2 565, 5/2/4 2 553, 3/2/6 2 545, 4/3/4 2 530, 23-bit layouts (three
+// passes) 3/1/4 2 402 and 4/0/4 2 410.  Before the foot point: direction-major or finer-cell keys of 27-30 bits 2 114-2 301 (no gain), RT_KEY_LEGACY
+// variants 1, 3, 4 no better than 2.
+#ifndef RT_KEY_CELL
+#define RT_KEY_CELL 4
+#endif
+#ifndef RT_KEY_DIR
+#define RT_KEY_DIR 2
+#endif
+#ifndef RT_KEY_FOOT
+#define RT_KEY_FOOT 5
+#endif
+RT_DEV uint32_t spread5(uint32_t v) { v &= 31u; v = (v | (v << 8)) & 0x100Fu; v = (v | (v << 4)) & 0x10C3u; v = (v | (v << 2)) & 0x1249u; return v; }   // bit k -> bit 3k
+RT_DEV uint32_t spread10x2(uint32_t x) { x &= 0x3FFu; x = (x | (x << 8)) & 0x00FF00FFu; x = (x | (x << 4)) & 0x0F0F0F0Fu; x = (x | (x << 2)) & 0x33333333u; x = (x | (x << 1)) & 0x55555555u; return x; }   // bit k -> bit 2k
 RT_DEV uint32_t sort_key(const SceneDev& sc, d3 o, d3 d) {
     const uint32_t oct = (d.x < 0.0 ? 1u : 0u) | (d.y < 0.0 ? 2u : 0u) | (d.z < 0.0 ? 4u : 0u);
-    const float fx = ((float)o.x - sc.sort_min[0]) * sc.sort_scale[0], fy = ((float)o.y - sc.sort_min[1]) * sc.sort_scale[1], fz = ((float)o.z - sc.sort_min[2]) * sc.sort_scale[2];
+    const float fx = ((float)o.x - sc.sort_min[0]) * sc.sort_scale[0], fy = ((float)o.y - sc.sort_min[1]) * sc.sort_scale[1], fz = ((float)o.z - sc.sort_min[2]) * sc.sort_scale[2];   // grid coordinates, 32 cells per axis
     const uint32_t cx = (uint32_t)fminf(fmaxf(fx, 0.f), 31.f), cy = (uint32_t)fminf(fmaxf(fy, 0.f), 31.f), cz = (uint32_t)fminf(fmaxf(fz, 0.f), 31.f);
-    // direction bin inside the octant (2 bits per axis of |d| / max|d|), least significant: rays leaving one cell in
-    // similar directions tend to share their fate (first hit or none), which is what keeps a wave's lanes busy
-    // after the first hits.  Measured against octant|cell alone: -2.5 % bench time; direction-major or finer
-    // grids (6 bits per axis) were no better.
     const float ax = fabsf((float)d.x), ay = fabsf((float)d.y), az = fabsf((float)d.z);
-    const float inv = 3.999f / fmaxf(fmaxf(ax, ay), fmaxf(az, 1e-30f));
-    const uint32_t dbin = ((uint32_t)(ax * inv) & 3u) | (((uint32_t)(ay * inv) & 3u) << 2) | (((uint32_t)(az * inv) & 3u) << 4);
-#ifndef RT_KEY_VARIANT
-#define RT_KEY_VARIANT 2  /* measured with strict pruning, 16 spp: variant 2 -4 % trace time against 1, variants 3 and 4 no better than 1 */
-#endif
-    const uint32_t morton = spread5(cx) | (spread5(cy) << 1) | (spread5(cz) << 2);
-#if RT_KEY_VARIANT == 1
-    return (oct << 21) | (morton << 6) | dbin;
-#elif RT_KEY_VARIANT == 2   // coarser cells (4 bits per axis), finer directions (3 bits per axis)
-    const float inv8 = 7.999f / fmaxf(fmaxf(ax, ay), fmaxf(az, 1e-30f));
+    const float amax = fmaxf(fmaxf(ax, ay), fmaxf(az, 1e-30f));
+#ifdef RT_KEY_LEGACY   /* the 24-bit key of r01-r03p, for A/B: octant | cell 4 | direction 3 */
+    const float inv8 = 7.999f / amax;
     const uint32_t d9 = ((uint32_t)(ax * inv8) & 7u) | (((uint32_t)(ay * inv8) & 7u) << 3) | (((uint32_t)(az * inv8) & 7u) << 6);
     const uint32_t m4 = spread5(cx >> 1) | (spread5(cy >> 1) << 1) | (spread5(cz >> 1) << 2);
     return (oct << 21) | ((m4 & 0xFFFu) << 9) | d9;
-#elif RT_KEY_VARIANT == 3   // origin-major
-    return (morton << 9) | (oct << 6) | dbin;
-#elif RT_KEY_VARIANT == 4   // cell, then direction, Morton-interleaved pairs: 3 origin bits, then octant, then the rest
-    return ((morton >> 9) << 18) | (oct << 15) | ((morton & 0x1FFu) << 6) | dbin;
+#else
+    const uint32_t cq = 5u - RT_KEY_CELL;
+    const uint32_t cell = spread5(cx >> cq) | (spread5(cy >> cq) << 1) | (spread5(cz >> cq) << 2);
+    const float invd = ((float)(1u << RT_KEY_DIR) - 0.001f) / amax;
+    const uint32_t dm = (1u << RT_KEY_DIR) - 1u;
+    const uint32_t dbin = RT_KEY_DIR ? (((uint32_t)(ax * invd) & dm) | (((uint32_t)(ay * invd) & dm) << RT_KEY_DIR) | (((uint32_t)(az * invd) & dm) << (2 * RT_KEY_DIR))) : 0u;
+    // foot point: r = o - centre in world units per axis, minus its component along the unit direction, back to grid units (0.5 = the centre)
+    const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+    const float il = 1.0f / fmaxf(__builtin_sqrtf(dx * dx + dy * dy + dz * dz), 1e-30f);
+    const float nx = dx * il, ny = dy * il, nz = dz * il;
+    const float rx = ((float)o.x - sc.sort_min[0]) - 16.0f / sc.sort_scale[0], ry = ((float)o.y - sc.sort_min[1]) - 16.0f / sc.sort_scale[1], rz = ((float)o.z - sc.sort_min[2]) - 16.0f / sc.sort_scale[2];
+    const float along = rx * nx + ry * ny + rz * nz;
+    const float gx = (rx - along * nx) * sc.sort_scale[0] * (1.0f / 32.0f) + 0.5f, gy = (ry - along * ny) * sc.sort_scale[1] * (1.0f / 32.0f) + 0.5f, gz = (rz - along * nz) * sc.sort_scale[2] * (1.0f / 32.0f) + 0.5f;
+    const uint32_t dom = (ax >= ay && ax >= az) ? 0u : (ay >= az ? 1u : 2u);
+    const float fu = dom == 0u ? gy : gx, fv = dom == 2u ? gy : gz;
+    const float ftop = (float)((1u << RT_KEY_FOOT) - 1u);
+    const uint32_t qu = (uint32_t)fminf(fmaxf(fu * (float)(1u << RT_KEY_FOOT), 0.f), ftop), qv = (uint32_t)fminf(fmaxf(fv * (float)(1u << RT_KEY_FOOT), 0.f), ftop);
+    const uint32_t foot = spread10x2(qu) | (spread10x2(qv) << 1);
+    return ((((oct << (3 * RT_KEY_CELL)) | cell) << (3 * RT_KEY_DIR)) | dbin) << (2 * RT_KEY_FOOT) | foot;
 #endif
 }
-#define RT_SORT_BITS 24u  /* octant (3) | origin cell (12) | direction bin (9): three 8-bit digit passes */
+#ifdef RT_KEY_LEGACY
+#define RT_SORT_BITS 24u
+#else
+#define RT_SORT_BITS (3u + 3u * RT_KEY_CELL + 3u * RT_KEY_DIR + 2u * RT_KEY_FOOT)
+#endif
+static_assert(RT_SORT_BITS <= 32u && RT_KEY_CELL <= 5 && RT_KEY_FOOT <= 10, "the sort key is one 32-bit word");
 
 RT_DEV void push_queue_keyed(bool want, uint32_t path, uint32_t key, uint32_t* __restrict__ queue, uint32_t* __restrict__ keys, uint32_t* __restrict__ count) {
     const uint64_t m = __ballot(want);

@@ -38,6 +38,7 @@ struct LaneCount {
 // part }.  A ray's visited records do not depend on its wave-mates, so the log gives every sampled ray's exact visited set and any regrouping
 // of those rays can be costed offline (tools/lane_log.py): the union of the visited offsets of a group is the step count of a wave made of it.
 __device__ uint4* g_dlog; __device__ unsigned int g_dlog_n, g_dlog_cap, g_dlog_every, g_dlog_group;
+__device__ float* g_dray; __device__ unsigned int g_dray_n, g_dray_cap;   // the sampled waves' rays: 8 floats each = { bits of wave * 64 + lane, o.xyz, d.xyz, t_light or 0 } (tools/key_eval.py)
 RT_DEV void diag_log(uint32_t wave, uint32_t off, uint64_t m) {
     if (wave != 0xFFFFFFFFu && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) {
         const unsigned int i = atomicAdd(&g_dlog_n, 1u);
@@ -1015,6 +1016,15 @@ __global__ __launch_bounds__(RT_TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(
 #ifdef RT_TRACE_DIAG
     cnt.steps = cnt.leaf_steps = cnt.cyc_wait = cnt.lane_steps = cnt.exact_box = cnt.exact_tri = 0; cnt.cyc_xbox = cnt.cyc_xtri = cnt.cyc_setup = cnt.cyc_leaf = cnt.leaf_open = 0; cnt.cyc_total = __builtin_readcyclecounter(); cnt.diag_flags = 0;
     cnt.dlog_wave = (g_dlog != nullptr && !COUNT && ((tid >> 6) / g_dlog_group % g_dlog_every) == 0u) ? (tid >> 6) : 0xFFFFFFFFu;   // groups of consecutive waves
+    if (cnt.dlog_wave != 0xFFFFFFFFu && g_dray != nullptr && valid) {
+        const unsigned int i = atomicAdd(&g_dray_n, 1u);
+        if (i < g_dray_cap) {
+            const RayS r = src.get();
+            float* q = g_dray + 8u * (size_t)i;
+            q[0] = __builtin_bit_cast(float, tid); q[1] = (float)r.o.x; q[2] = (float)r.o.y; q[3] = (float)r.o.z; q[4] = (float)r.d.x; q[5] = (float)r.d.y; q[6] = (float)r.d.z;
+            q[7] = SHADOW ? (float)src.tl() : 0.f;
+        }
+    }
 #endif
     if (REGS) {
         LaneHitRegs hr; hr.best = t_max; hr.prim = RT_NONE; hr.inst = RT_NONE;
