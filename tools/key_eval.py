@@ -155,6 +155,19 @@ def refined_keys(o, d, grid):
     for ab in (3, 5):      # position of the origin ALONG the line (grid units of the dominant axis), coarse
         a = along[:, 0] * sscale[dom] * f32(1.0 / 32.0) + f32(0.5)
         out["production | position along the line, %d bits" % ab] = (prod << ab) | np.clip((a * f32(1 << ab)).astype(np.int64), 0, (1 << ab) - 1)
+    # other LAYOUTS (their major bits differ from production's, so re-sorting inside a production group only approximates the global sort: "~")
+    m3, _ = cellbits(3); m2, _ = cellbits(2); m5, _ = cellbits(5); d1, _ = dirbits(1); d3, _ = dirbits(3)
+    out["~ octant|cell3|dir2|foot5+5"] = (((((octant << 9) | m3) << 6) | d2) << 10) | footbits(5)
+    out["~ octant|cell3|dir2|foot6+6"] = (((((octant << 9) | m3) << 6) | d2) << 12) | footbits(6)
+    out["~ octant|cell2|dir2|foot6+6"] = (((((octant << 6) | m2) << 6) | d2) << 12) | footbits(6)
+    out["~ octant|dir2|foot5+5|cell4"] = (((((octant << 6) | d2) << 10) | footbits(5)) << 12) | m4
+    out["~ octant|dir2|foot4+4|cell4"] = (((((octant << 6) | d2) << 8) | footbits(4)) << 12) | m4
+    out["~ octant|dom|foot6+6|cell3"] = (((((octant << 2) | dom) << 12) | footbits(6)) << 9) | m3
+    out["~ octant|cell4|dir1|foot5+5"] = (((((octant << 12) | m4) << 3) | d1) << 10) | footbits(5)
+    out["~ octant|dom|cell4|foot5+5"] = (((((octant << 2) | dom) << 12) | m4) << 10) | footbits(5)
+    out["~ octant|cell5|dir2|foot4+4"] = (((((octant << 15) | m5) << 6) | d2) << 8) | footbits(4)
+    out["~ octant|cell4|dir3|foot4+4"] = (((((octant << 12) | m4) << 9) | d3) << 8) | footbits(4)
+    out["~ octant|dir2|cell2|foot5+5|cell+2"] = (((((((octant << 6) | d2) << 6) | m2) << 10) | footbits(5)) << 6) | low3(cellbits(4)[1], 2)
     qu, qv = footq(6); m = 1
     out["production | foot +1 | cell +1 bits/axis"] = (((prod << 2) | spread(qu & m, 1) | (spread(qv & m, 1) << 1)) << 3) | low3(cellbits(5)[1], 1)
     return out
