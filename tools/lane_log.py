@@ -41,6 +41,14 @@ def analyse(path):
     steps = len(wave)
     out = {"file": os.path.basename(path), "sampled_waves": int(len(np.unique(wave))), "steps": steps,
            "lane_use": float(act.sum() / (64.0 * steps)), "per_lane_floor_steps": float(act.sum() / 64.0)}
+    per_wave = np.bincount(np.unique(wave, return_inverse=True)[1])
+    mean = per_wave.mean()
+    out["steps_per_wave"] = {"mean": round(float(mean), 1), "p50": int(np.percentile(per_wave, 50)), "p90": int(np.percentile(per_wave, 90)), "p99": int(np.percentile(per_wave, 99)),
+                             "p99.9": int(np.percentile(per_wave, 99.9)), "max": int(per_wave.max()),
+                             "share_of_steps_in_waves_over_4x_mean": round(float(per_wave[per_wave > 4 * mean].sum() / per_wave.sum()), 4),
+                             "waves_over_4x_mean": round(float((per_wave > 4 * mean).mean()), 5),
+                             "share_of_steps_in_waves_over_10x_mean": round(float(per_wave[per_wave > 10 * mean].sum() / per_wave.sum()), 4),
+                             "waves_over_10x_mean": round(float((per_wave > 10 * mean).mean()), 5)}
     edges = [0, 1, 2, 3, 5, 9, 17, 33, 65]
     names = ["0", "1", "2", "3-4", "5-8", "9-16", "17-32", "33-64"]
     h, _ = np.histogram(act, bins=edges)
@@ -141,6 +149,7 @@ def main():
         if r is None:
             continue
         print(r["file"], "waves", r["sampled_waves"], "steps", r["steps"], "lane use %.3f" % r["lane_use"], "per-lane floor %.3f" % (r["per_lane_floor_steps"] / r["steps"]))
+        print("   steps per wave:", r["steps_per_wave"])
         print("   steps by participating lanes:", r["steps_by_lanes"])
         print("   steps by live lanes:         ", r["steps_by_live_lanes"])
         print("   ray-stream bound (steps / today's) by block of G waves:", r["ray_stream_bound_steps_ratio_by_block_waves"])
