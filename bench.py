@@ -4,7 +4,8 @@
 (main.rs:944), 1000 spp = configs[2], which fits one GPU.
 
 A "step" is --spp-per-step samples of every pixel (ray-gen -> [traverse -> shade -> traverse shadow rays] x depth -> unwind ->
-accumulate); the default 50 makes the driver's `--steps 20` exactly the 1000-spp frame, and ms_per_step = time / steps.
+accumulate); the default 50 makes the driver's `--steps 20` exactly the 1000-spp frame, and ms_per_step = time / steps (how the renderer batches the
+frame's samples into jobs is its own business: --job-spp).
 The samples are rendered as JOBS queued with rt_render_begin and waited for with rt_render_end, two in flight (one pass each, on
 the scene's two lanes): the thin deep bounces of one job overlap the other job's kernels; --sync-steps runs blocking rt_render
 calls (two lanes of half-size passes inside each call) instead.  Inputs (the flattened scene) are resident in HBM before the timed
@@ -12,8 +13,8 @@ region; accumulators stay on the device.
 
 N ranks (main.rs:1009-1011: tonemap after the sum): `--scaling strong` (default) renders THE frame -- the
 steps x spp_per_step absolute sample indices [0, S) -- split as contiguous per-rank ranges [floor(S r/N), floor(S (r+1)/N));
-every rank cuts its range into jobs of at least spp_per_step samples (125 spp on 8 ranks = 2 jobs of 62 and 63), so job size
-does not shrink with N.  `--scaling weak` gives every rank its own S samples (rank r: [S r, S (r+1))).  One broadcast of the
+every rank cuts its range into jobs of at least spp_per_step samples, as large as one pass per lane allows (--job-spp 0: 72 spp at 1080p, so the
+1000-spp frame is 14 jobs of 71-72 on one rank and 2 jobs of 62 and 63 on each of 8), so job size does not shrink with N.  `--scaling weak` gives every rank its own S samples (rank r: [S r, S (r+1))).  One broadcast of the
 scene bytes before, one all-reduce of the fp32 sums inside the timed region (reported separately as allreduce_ms).
 
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (child processes,
@@ -62,6 +63,9 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="pagoda_1080p_mis", choices=sorted(WORKLOADS))
     ap.add_argument("--spp-per-step", type=int, default=50)       # x the driver's 20 steps = the 1000 spp of the metric
+    # how a rank cuts its samples into jobs (one pass each, two in flight): 0 = auto -- as large as one pass per lane allows (72 spp at 1080p, depth 5),
+    # never below spp_per_step; N = jobs of about N samples (--job-spp 10 with --spp-per-step 10: one 10-spp FRAME per call, configs[0] at its own size)
+    ap.add_argument("--job-spp", type=int, default=0)
     # strong (default): the frame of steps x spp_per_step samples, split over the ranks as contiguous sample ranges;
     # weak: every rank renders steps x spp_per_step samples of its own.  The same thing on one rank.
     ap.add_argument("--scaling", default="strong", choices=("weak", "strong"))
@@ -86,13 +90,23 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def plan_jobs(b, e, job_spp):
-    """Cuts the sample range [b, e) into max(1, (e-b) // job_spp) contiguous jobs of near-equal size: every job has at least
-    job_spp samples (unless the whole range is smaller), so the per-launch ray counts do not shrink with the number of ranks."""
+def plan_jobs(b, e, job_spp, job_max=0):
+    """Cuts the sample range [b, e) into contiguous jobs of near-equal size.  Every job has at least job_spp samples (unless the whole range is
+    smaller), so the per-launch ray counts do not shrink with the number of ranks.  job_max > job_spp: jobs as large as job_max allows -- the fewest
+    jobs of at most job_max samples, an even number of them when there are several (two are in flight: an odd one out would run alone) -- because a
+    pass's deeper bounces are the denser, and the cheaper per ray, the more samples it holds (25 / 50 / 100 spp per pass cost
+    2.65 / 2.32 / 2.10 ms per sample).  Otherwise max(1, (e-b) // job_spp) jobs."""
     n = e - b
     if n <= 0:
         return []
-    k = max(1, n // max(job_spp, 1))
+    job_spp = max(job_spp, 1)
+    k = max(1, n // job_spp)
+    if job_max > job_spp:
+        kk = -(-n // job_max)
+        if kk > 1 and kk % 2:
+            kk += 1
+        if kk == 1 or n // kk >= job_spp:
+            k = kk
     return [(b + (i * n) // k, b + ((i + 1) * n) // k) for i in range(k)]
 
 
@@ -198,10 +212,18 @@ class HipRenderer:
         return self.gs.render_begin(accum.data_ptr(), self.W, self.H, b, e, self.depth, self.integrator, seed=0x5EED, samples_per_pass=samples_per_pass,
                                     flags=self.flags)
 
+    LANE_BYTES = 112 << 30   # path state per lane: two lanes + scene + certificate tables stay under the 288 GB
+
+    def bytes_per_sample(self):
+        return self.W * self.H * (self.depth * 96 + 320)     # depth x 96 B of bounce records + 320 B per path
+
     def pass_size_for(self, n_spp):
-        """A job of n_spp samples runs as ONE pass when its path state (depth x 96 B of bounce records + 320 B per path) fits 112 GiB per
-        lane (two lanes + scene + certificate tables stay under the 288 GB); otherwise the library's default pass size (0)."""
-        return n_spp if n_spp * self.W * self.H * (self.depth * 96 + 320) <= (112 << 30) and n_spp * self.W * self.H < (128 << 20) else 0
+        """A job of n_spp samples runs as ONE pass when its path state fits LANE_BYTES; otherwise the library's default pass size (0)."""
+        return n_spp if n_spp * self.bytes_per_sample() <= self.LANE_BYTES and n_spp * self.W * self.H < 0x7FFFFF00 else 0
+
+    def max_job_spp(self):
+        """The largest job that still runs as one pass per lane (1080p, depth 5: 72 spp)."""
+        return max(1, min(self.LANE_BYTES // self.bytes_per_sample(), (0x7FFFFF00 - 1) // (self.W * self.H)))
 
     def end(self, job):
         return self.gs.render_end(job).as_dict()
@@ -291,8 +313,10 @@ def main():
     frame_spp = args.steps * spp_step                      # the frame: absolute sample indices [0, frame_spp)
     shard_rank, shard_world = rehearse if rehearse else (rank, world)
     my_b, my_e = rank_range(args.scaling, shard_rank, shard_world, frame_spp)
-    jobs = plan_jobs(my_b, my_e, spp_step)                 # this rank's share as jobs of >= spp_per_step samples
     pass_size = getattr(R, "pass_size_for", lambda n: 0)
+    job_min = args.job_spp if args.job_spp > 0 else spp_step
+    job_max = 0 if args.job_spp > 0 or not hasattr(R, "max_job_spp") else R.max_job_spp()
+    jobs = plan_jobs(my_b, my_e, job_min, job_max)         # this rank's share as jobs of >= spp_per_step samples, one pass each where memory allows
     # warm-up: `--warmup` jobs of this rank's largest job size (so the path buffers the timed jobs need exist), on sample indices past
     # every rank's share; their sums are thrown away
     big = max((e - b for b, e in jobs), default=spp_step)
@@ -362,7 +386,7 @@ def main():
         "data": "synthetic (reference pagoda OBJ asset, Lambertian 0.5 albedo; Philox-seeded camera samples)",
         "config": {"workload": args.workload, "scene": scene, "width": W, "height": H, "integrator": INTEGRATOR_NAMES[integrator],
                    "max_depth": depth, "spp_per_step": spp_step, "render_lanes": 1 if args.one_lane else 2, "spp_total": spp_total,
-                   "frame_spp": frame_spp, "jobs_in_flight": 2 if pipelined else 1,
+                   "frame_spp": frame_spp, "jobs_in_flight": 2 if pipelined else 1, "job_spp": "auto" if args.job_spp <= 0 else args.job_spp,
                    "sharding": ("none" if world == 1 else
                                 f"spp-range x{world}: rank r renders samples [floor({frame_spp}r/{world}), floor({frame_spp}(r+1)/{world})) of the frame, as jobs of >= {spp_step} spp"
                                 if args.scaling == "strong" else
@@ -387,18 +411,19 @@ def main():
             out["cpu_baseline"] = cpu_baseline(R.desc, integrator, depth, threads)
     R.close()
     if world == 1 and not rehearse and not args.renderer and args.bvh_axis != "seeded" and not args.no_seeded_compare:
-        out["seeded_tree"] = seeded_compare(args, local_rank, dev, rtd, accum, sync, spp_step)
+        out["seeded_tree"] = seeded_compare(args, local_rank, dev, rtd, accum, sync, max((e - b for b, e in jobs), default=spp_step))
     print(json.dumps(out), flush=True)
     return 0
 
 
 def seeded_compare(args, local_rank, dev, rtd, accum, sync, spp_step):
-    """After the timed region and after its scene is closed: the same steps on the tree of the seeded axis stream (the tree of the
-    parity suites and of rounds 1-2a), two warm-up and four timed steps, so the line shows what the axis choice is worth."""
+    """After the timed region and after its scene is closed: jobs of the timed region's size on the tree of the seeded axis stream (the tree of
+    the parity suites and of rounds 1-2a), two warm-up and four timed jobs, so the line shows what the axis choice is worth."""
     R = HipRenderer(args, 0, 1, local_rank, dev, rtd, bvh_axis="seeded")
     try:
         def pair(b):
-            jobs = [R.begin(accum, b, b + spp_step), R.begin(accum, b + spp_step, b + 2 * spp_step)]
+            ps = R.pass_size_for(spp_step)
+            jobs = [R.begin(accum, b, b + spp_step, samples_per_pass=ps), R.begin(accum, b + spp_step, b + 2 * spp_step, samples_per_pass=ps)]
             return [R.end(j) for j in jobs]
         pair(0); sync()
         t0 = time.perf_counter()

@@ -83,8 +83,9 @@ def test_kernel_trace_summary_beside_it_names_the_roofline_kernel():
     r = p["roofline"]
     calls, total_ms = sum(int(x["Calls"]) for x in trace), sum(float(x["TotalDurationNs"]) for x in trace) / 1e6
     timed = r["launches"]
-    per_step = timed // p["steps"]
-    extra = calls - timed - p["warmup"] * per_step      # the untimed one-lane step, and (from r02h on) the step that counts record steps
+    jobs = len(p["config"].get("rank0_jobs_spp") or []) or p["steps"]      # from r03w on a job is as large as a lane's pass allows, not one --spp-per-step
+    per_step = timed // jobs                                               # launches per job (one pass each): warm-up and the two extra runs are whole jobs
+    extra = calls - timed - p["warmup"] * per_step      # the untimed one-lane job, and (from r02h on) the job that counts record steps
     assert extra in (per_step, 2 * per_step), (calls, timed, extra)
     # the counting step's launches run like the timed ones (two lanes inside the call), a few percent slower for their counter: priced at the timed average
     shared_avg = (total_ms - per_step * r["one_lane"]["avg_launch_ms"] - (extra - per_step) * r["avg_launch_ms"]) / (calls - extra)

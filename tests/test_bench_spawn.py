@@ -33,6 +33,13 @@ def test_plan_jobs_keeps_jobs_at_least_a_step_large():
     assert bench.plan_jobs(0, 1000, 50) == [(50 * i, 50 * i + 50) for i in range(20)]
     assert bench.plan_jobs(125, 250, 50) == [(125, 187), (187, 250)]          # 125 spp on 8 ranks: two jobs of 62 and 63, not 6-spp slivers
     assert bench.plan_jobs(0, 30, 50) == [(0, 30)] and bench.plan_jobs(7, 7, 50) == []
+    # with a memory-bound job size (72 spp at 1080p): the fewest jobs that fit, an even number of them, never below a step
+    big = bench.plan_jobs(0, 1000, 50, 72)
+    assert len(big) == 14 and {e - b for b, e in big} == {71, 72} and big[0][0] == 0 and big[-1][1] == 1000
+    assert bench.plan_jobs(125, 250, 50, 72) == [(125, 187), (187, 250)]      # 8 ranks: unchanged
+    assert [e - b for b, e in bench.plan_jobs(0, 500, 50, 72)] == [62, 63, 62, 63, 62, 63, 62, 63]   # 7 jobs of 72 would leave one alone: 8 of 62-63
+    assert bench.plan_jobs(0, 60, 50, 72) == [(0, 60)] and bench.plan_jobs(0, 100, 50, 72) == [(0, 50), (50, 100)]
+    assert bench.plan_jobs(0, 200, 25, 18) == bench.plan_jobs(0, 200, 25)     # a 4K frame: one pass per job does not fit, jobs stay at a step
     for world in (1, 2, 3, 4, 8, 16):                                        # the ranks' shares tile the frame exactly
         cuts = [bench.rank_range("strong", r, world, 1000) for r in range(world)]
         assert cuts[0][0] == 0 and cuts[-1][1] == 1000 and all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
