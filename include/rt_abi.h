@@ -193,7 +193,7 @@ typedef struct rt_stats {
     uint64_t box_tests;  /* only with RT_RENDER_COUNT_TESTS / rt_trace_closest counters */
     uint64_t tri_tests;
     uint64_t sphere_tests;
-    uint64_t launches;   /* kernel launches issued */
+    uint64_t launches;   /* kernel launches issued (a radix sort of a queue counts as one) */
     double ms_total;     /* first ray-gen launch -> accumulators final (HIP events on the context stream) */
     double ms_trace;     /* sum over trace_closest launches (HIP events on the launching stream; launches of the two lanes
                           * overlap, so the sums of both lanes can exceed ms_total) */

@@ -534,14 +534,14 @@ static int run_paths(rt_scene* sc, Workspace& ws, hipStream_t st, uint32_t n, bo
             next_live = std::min(ws.h_counts[2 * (size_t)bounce + 2], n); shadow_live = std::min(ws.h_counts[2 * (size_t)bounce + 1], n);
         }
         const bool do_shadow = mis_shadow && shadow_live;
-        if (sorted && do_shadow) { int rc = sort_queue(ws, st, shadow_live, ws.raw_skeys, ws.raw_squeue, ws.shadow_queue); if (rc != RT_OK) return rc; }   // the sorted order lands in shadow_queue
+        if (sorted && do_shadow) { int rc = sort_queue(ws, st, shadow_live, ws.raw_skeys, ws.raw_squeue, ws.shadow_queue); if (rc != RT_OK) return rc; launches += 1; }   // the sorted order lands in shadow_queue
         hipStream_t sst = st;
         if (do_shadow && side) {   // everything the shadow traversal reads is in place on the main stream here
             HIP_OK(hipEventRecord(ws.ev_shaded, st));
             HIP_OK(hipStreamWaitEvent(ws.side, ws.ev_shaded, 0));
             sst = ws.side;
         }
-        if (sorted && !last_bounce && next_live) { int rc = sort_queue(ws, st, next_live, ws.raw_keys, ws.raw_queue, ws.queue[nxt]); if (rc != RT_OK) return rc; }
+        if (sorted && !last_bounce && next_live) { int rc = sort_queue(ws, st, next_live, ws.raw_keys, ws.raw_queue, ws.queue[nxt]); if (rc != RT_OK) return rc; launches += 1; }
         if (!small) tm.end();
         launches += 2;
         if (do_shadow) {
@@ -1093,6 +1093,81 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
             v.sort_min[k] = (float)(mean - 0.5 * ext);
             v.sort_scale[k] = (float)(32.0 / ext);
         }
+        // a handful of scene-level leaves that are INSTANCES (cornell: six transformed cubes and a ground sphere, `main.rs:161-188`): every sub-walk a wave
+        // enters is paid by all 64 lanes (ray transform, filter set-up, 23 records), so rays that go the same way are worth a sort here too.  Moments of
+        // seven centres mean nothing (the ground sphere alone puts the whole room into one cell): the grid is the union of the leaf boxes that are not
+        // outliers -- no axis longer than 8 x the median extent of that axis over the leaves
+        if (!sc->sortable && sc->has_instances && !getenv("RT_NO_SMALL_SORT")) {
+            // world box of a scene-level leaf's object (the list items of `hittable.rs:41-53` carry no box): an instance's is its sub-BVH's root box
+            // taken through the forward transform (the blob holds the inverse only; a sort grid needs no exact bits), a sphere's is centre +- radius
+            struct Box { double lo[3], hi[3]; };
+            std::vector<Box> boxes;
+            const rt_xform* xf = (const rt_xform*)(b + h.off_xforms);
+            const rt_geom* geom = (const rt_geom*)(b + h.off_geom);
+            auto object_box = [&](uint32_t p, Box& bx) -> bool {
+                if (p == RT_NONE || p >= h.n_prims) return false;
+                double olo[3], ohi[3];
+                if (prims[p].kind == RT_PRIM_INSTANCE && prims[p].index < h.n_nodes) {
+                    const rt_node& r = nodes[prims[p].index];
+                    for (int k = 0; k < 3; ++k) { olo[k] = r.bmin[k]; ohi[k] = r.bmax[k]; }
+                } else if (prims[p].kind == RT_PRIM_SPHERE) {
+                    for (int k = 0; k < 3; ++k) { olo[k] = geom[p].d[k] - std::fabs(geom[p].d[3]); ohi[k] = geom[p].d[k] + std::fabs(geom[p].d[3]); }
+                } else return false;
+                for (int k = 0; k < 3; ++k) if (!std::isfinite(olo[k]) || !std::isfinite(ohi[k])) return false;
+                if (prims[p].xform == RT_NONE || prims[p].xform >= h.n_xforms) { for (int k = 0; k < 3; ++k) { bx.lo[k] = olo[k]; bx.hi[k] = ohi[k]; } return true; }
+                const double* m = xf[prims[p].xform].t_inv;   // column-major: m[4 c + r]
+                double a3[3][3], f[3][3];
+                for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) a3[r][c] = m[4 * c + r];
+                const double det = a3[0][0] * (a3[1][1] * a3[2][2] - a3[1][2] * a3[2][1]) - a3[0][1] * (a3[1][0] * a3[2][2] - a3[1][2] * a3[2][0]) +
+                                   a3[0][2] * (a3[1][0] * a3[2][1] - a3[1][1] * a3[2][0]);
+                if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) return false;
+                for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
+                    const int r1 = (c + 1) % 3, r2 = (c + 2) % 3, c1 = (r + 1) % 3, c2 = (r + 2) % 3;   // adjugate: cofactor of (c, r)
+                    f[r][c] = (a3[r1][c1] * a3[r2][c2] - a3[r1][c2] * a3[r2][c1]) / det;
+                }
+                for (int k = 0; k < 3; ++k) { bx.lo[k] = INFINITY; bx.hi[k] = -INFINITY; }
+                for (int corner = 0; corner < 8; ++corner) {
+                    double q[3];
+                    for (int k = 0; k < 3; ++k) q[k] = ((corner >> k) & 1 ? ohi[k] : olo[k]) - m[12 + k];   // world = F (object - t_inv's translation)
+                    for (int r = 0; r < 3; ++r) {
+                        const double w = f[r][0] * q[0] + f[r][1] * q[1] + f[r][2] * q[2];
+                        if (!std::isfinite(w)) return false;
+                        bx.lo[r] = std::min(bx.lo[r], w); bx.hi[r] = std::max(bx.hi[r], w);
+                    }
+                }
+                return true;
+            };
+            for (uint32_t i = h.root_node; i < h.root_end; ++i) {
+                const rt_node& nd = nodes[i];
+                if (nd.prim0 == RT_NONE) continue;
+                Box b;
+                if (object_box(nd.prim0, b)) boxes.push_back(b);
+                if (nd.prim1 != RT_NONE && nd.prim1 != nd.prim0 && object_box(nd.prim1, b)) boxes.push_back(b);
+            }
+            double med[3] = {0, 0, 0}, lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (int k = 0; k < 3 && !boxes.empty(); ++k) {
+                std::vector<double> e;
+                for (const Box& b : boxes) e.push_back(b.hi[k] - b.lo[k]);
+                std::sort(e.begin(), e.end()); med[k] = e[e.size() / 2];
+            }
+            uint32_t kept = 0;
+            for (const Box& b : boxes) {
+                bool in = true;
+                for (int k = 0; k < 3; ++k) in = in && (b.hi[k] - b.lo[k]) <= 8.0 * med[k];
+                if (!in) continue;
+                ++kept;
+                for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); }
+            }
+            if (kept >= 2) {
+                sc->sortable = true;
+                for (int k = 0; k < 3; ++k) {
+                    double e = std::max(hi[k] - lo[k], 1e-6);
+                    v.sort_min[k] = (float)lo[k];
+                    v.sort_scale[k] = (float)(32.0 / e);
+                }
+            }
+        }
+        if (getenv("RT_PRINT_SORTGRID")) fprintf(stderr, "[sortgrid] sortable %d  min %.6g %.6g %.6g  cells per unit %.6g %.6g %.6g\n", (int)sc->sortable, v.sort_min[0], v.sort_min[1], v.sort_min[2], v.sort_scale[0], v.sort_scale[1], v.sort_scale[2]);
 #ifdef RT_TRACE_DIAG
         fprintf(stderr, "[diag-sortgrid] %.9g %.9g %.9g %.9g %.9g %.9g\n", v.sort_min[0], v.sort_min[1], v.sort_min[2], v.sort_scale[0], v.sort_scale[1], v.sort_scale[2]);
 #endif

@@ -150,6 +150,22 @@ def test_per_lane_walk_gives_the_frame_of_the_wave_walk(gpu_ctx, name, integ, w,
     gs.close()
 
 
+@pytest.mark.parametrize("name,integ,w,h,spp", [("cornell", rt.INT_MIS, 480, 270, 16), ("cornell", rt.INT_BRDF, 480, 270, 16), ("mesh", rt.INT_MIS, 480, 270, 6)])
+def test_sorted_bounce_queues_give_the_frame_of_unsorted_ones(gpu_ctx, name, integ, w, h, spp):
+    # bounce and shadow rays are radix-sorted by a coherence key before they are traced (scenes of >= 64 leaves; from r03x also scenes of a few
+    # INSTANCE leaves: cornell's grid is the union of its objects' world boxes without the ground sphere).  RT_RENDER_NO_SORT traces them in the
+    # order shading appended them: a path's radiance does not depend on its queue slot, so the accumulators are bit-identical.  One pass of
+    # > 2^20 paths, so that cornell's queues stay above the small-queue mode (which never sorts).
+    hs, _ = _pair(name)
+    gs = gpu_ctx.upload(hs)
+    a, sa = gs.render_host(w, h, 0, spp, 5, integ, seed=21, samples_per_pass=spp)
+    b, sb = gs.render_host(w, h, 0, spp, 5, integ, seed=21, samples_per_pass=spp, flags=rt.RENDER_NO_SORT)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert sa.rays == sb.rays and sa.paths == sb.paths == w * h * spp
+    assert sa.launches > sb.launches      # the sorts ran (and are counted)
+    gs.close()
+
+
 @pytest.mark.parametrize("name,integ,depth", [("random", rt.INT_MIS, 12), ("simple", rt.INT_BRDF, 6), ("sphere", rt.INT_LIGHT_IS, 5)])
 def test_material_binned_shading_gives_the_frame_of_queue_order(gpu_ctx, name, integ, depth):
     # opt-in RT_RENDER_MATERIAL_BINS: before every shade launch the queue's slots are regrouped by the material class of their hits
