@@ -95,18 +95,19 @@ def plan_jobs(b, e, job_spp, job_max=0):
     smaller), so the per-launch ray counts do not shrink with the number of ranks.  job_max > job_spp: jobs as large as job_max allows -- the fewest
     jobs of at most job_max samples, an even number of them when there are several (two are in flight: an odd one out would run alone) -- because a
     pass's deeper bounces are the denser, and the cheaper per ray, the more samples it holds (25 / 50 / 100 spp per pass cost
-    2.65 / 2.32 / 2.10 ms per sample).  Otherwise max(1, (e-b) // job_spp) jobs."""
+    2.65 / 2.32 / 2.10 ms per sample).  0 < job_max < job_spp (a step does not fit one pass: 4K, 25 spp against 18): jobs of at most job_max, each ONE
+    pass, instead of jobs of a step that run as three short passes (r03x: broken cube 4K +5 %).  job_max 0: max(1, (e-b) // job_spp) jobs."""
     n = e - b
     if n <= 0:
         return []
     job_spp = max(job_spp, 1)
     k = max(1, n // job_spp)
-    if job_max > job_spp:
+    if job_max > 0 and job_max != job_spp:
         kk = -(-n // job_max)
         if kk > 1 and kk % 2:
             kk += 1
-        if kk == 1 or n // kk >= job_spp:
-            k = kk
+        if job_max < job_spp or kk == 1 or n // kk >= job_spp:
+            k = min(kk, n)
     return [(b + (i * n) // k, b + ((i + 1) * n) // k) for i in range(k)]
 
 

@@ -39,7 +39,10 @@ def test_plan_jobs_keeps_jobs_at_least_a_step_large():
     assert bench.plan_jobs(125, 250, 50, 72) == [(125, 187), (187, 250)]      # 8 ranks: unchanged
     assert [e - b for b, e in bench.plan_jobs(0, 500, 50, 72)] == [62, 63, 62, 63, 62, 63, 62, 63]   # 7 jobs of 72 would leave one alone: 8 of 62-63
     assert bench.plan_jobs(0, 60, 50, 72) == [(0, 60)] and bench.plan_jobs(0, 100, 50, 72) == [(0, 50), (50, 100)]
-    assert bench.plan_jobs(0, 200, 25, 18) == bench.plan_jobs(0, 200, 25)     # a 4K frame: one pass per job does not fit, jobs stay at a step
+    # a 4K frame: a 25-spp step does not fit one pass (18 spp): jobs of ONE pass each, an even number, instead of jobs of three short passes
+    assert [e - b for b, e in bench.plan_jobs(0, 200, 25, 18)] == [16, 17, 17, 16, 17, 17, 16, 17, 17, 16, 17, 17]
+    assert [e - b for b, e in bench.plan_jobs(0, 25, 25, 18)] == [12, 13] and bench.plan_jobs(0, 3, 25, 1) == [(0, 1), (1, 2), (2, 3)]
+    assert bench.plan_jobs(0, 1000, 50, 50) == bench.plan_jobs(0, 1000, 50)
     for world in (1, 2, 3, 4, 8, 16):                                        # the ranks' shares tile the frame exactly
         cuts = [bench.rank_range("strong", r, world, 1000) for r in range(world)]
         assert cuts[0][0] == 0 and cuts[-1][1] == 1000 and all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
