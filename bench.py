@@ -344,6 +344,8 @@ def main():
 
     sync()
     run_jobs(warm_jobs)
+    if world > 1 and args.warmup > 0:
+        rtd.allreduce_accum(accum)     # the warm-up covers the collective too: the first all-reduce of a size sets the communicator's rings and buffers up
     accum.zero_()
     sync()
     if world > 1:
