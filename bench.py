@@ -322,9 +322,9 @@ def main():
     # every rank's share; their sums are thrown away
     big = max((e - b for b, e in jobs), default=spp_step)
     warm_first = max(shard_world, 1) * frame_spp
-    warm_jobs = [(warm_first + i * big, warm_first + (i + 1) * big) for i in range(args.warmup)]
-
     pipelined = hasattr(R, "begin") and not args.sync_steps and not args.one_lane
+    n_warm = 2 if (pipelined and args.warmup == 1) else args.warmup      # two jobs in flight: a single warm-up job would leave the second lane's ~100 GB of path buffers to be allocated inside the timed region
+    warm_jobs = [(warm_first + i * big, warm_first + (i + 1) * big) for i in range(n_warm)]
 
     def run_jobs(todo):
         """Renders the sample ranges of `todo` in order.  Pipelined: two jobs in flight (rt_render_begin / rt_render_end, one pass each on the

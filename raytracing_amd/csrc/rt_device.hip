@@ -863,6 +863,30 @@ static int prepare_scene(const void* blob, uint64_t nbytes, ScenePrep& P) {
             if (holds) { elide[i] = 1; ++P.n_elided; }
         }
     }
+    // The same argument lets ANY inner record go, and a wave-coherent walk gains from it whenever most waves that reach the record go on into it: the
+    // wave pays one step for the record and, if any of its 64 rays passes, both children anyway; without the record it pays the children always.  A box
+    // nearly as large as the one a ray had to pass to get here (median splits of long roofs and floors: chains of them from the root down) is passed
+    // by nearly every wave that reaches it.  Rule (found with tools/elide_eval.py on the step log of a real pass): no record
+    // for an inner node whose box has at least RT_ELIDE_AREA (default 0.7) of the surface area of its nearest ancestor that kept its record.
+    if (P.boxes_nested) {
+        const char* qs = getenv("RT_ELIDE_AREA");
+        const double q = qs ? atof(qs) : 0.7;
+        if (q > 0.0) {
+            auto half_area = [&](uint32_t i) {
+                const double x = std::max(nodes[i].bmax[0] - nodes[i].bmin[0], 0.0), y = std::max(nodes[i].bmax[1] - nodes[i].bmin[1], 0.0),
+                             z = std::max(nodes[i].bmax[2] - nodes[i].bmin[2], 0.0);
+                return x * y + y * z + z * x;
+            };
+            std::vector<double> kept_area((size_t)h.n_nodes, INFINITY);   // area of the nearest ancestor with a record (pre-order: parents come first)
+            for (uint32_t i = h.root_node; i < h.root_end; ++i) {
+                if (nodes[i].prim0 != RT_NONE) continue;
+                const double own = half_area(i);
+                if (!elide[i] && nodes[i].skip > i + 1 && std::isfinite(kept_area[i]) && own >= q * kept_area[i]) { elide[i] = 1; ++P.n_elided; }
+                const double down = elide[i] ? kept_area[i] : own;
+                for (uint32_t c = i + 1; c < nodes[i].skip && c < h.root_end; c = nodes[c].skip) kept_area[c] = down;
+            }
+        }
+    }
     { int rc = emit(elide, P.stream_prod, P.rec_off_prod, P.end_off_prod); if (rc != RT_OK) return rc; }
     P.root_off_prod = h.root_node == h.root_end ? P.end_off_prod[h.root_end] : P.rec_off_prod[h.root_node];
     static_assert(RT_STREAM_REC + 28 * 4 == RT_STREAM_REC_TRI2, "TRI2 record layout");
