@@ -238,10 +238,18 @@ int rt_scene_destroy(rt_scene* scene);
  * exists so that tests without a GPU can check what the kernel will walk. */
 int rt_stream_build_host(const void* blob, uint64_t nbytes, void* stream_out, uint64_t capacity, uint64_t* stream_bytes,
                          uint32_t* root_off, uint32_t* node_off);
-/* Same for the PRODUCTION stream the pruning kernel walks: inner nodes that can never be pruned and whose box holds
- * everything that can be have no record (node_off gives their first child's offset).  DESIGN.md section 5. */
+/* Same for the PRODUCTION stream the kernel walks: the reference's leaves in the reference's order under a hierarchy
+ * of this library's own (re-bracketed by surface area when the reference's boxes nest; inner nodes most waves enter anyway have no record).
+ * node_off = n_nodes + 1 offsets by the BLOB's node index: meaningful for leaves and instance sub-arrays (what the certificate and the
+ * instance walk look up); the node word of a record indexes the array rt_stream_nodes_prod_host returns. */
 int rt_stream_build_prod_host(const void* blob, uint64_t nbytes, void* stream_out, uint64_t capacity, uint64_t* stream_bytes,
                               uint32_t* root_off, uint32_t* node_off);
+/* The node array the production stream's records index: the blob's nodes, followed -- when the scene-level hierarchy was rebuilt -- by the
+ * new scene-level range [*range_begin, *range_end) in pre-order (copies of the leaves in the reference's order under new inner nodes whose
+ * boxes are the unions of their leaves').  nodes_out may be NULL to query *n_nodes_out; elided_out (may be NULL) = one byte per node, 1 = no
+ * record in the production stream.  Host only; no counterpart in the reference. */
+int rt_stream_nodes_prod_host(const void* blob, uint64_t nbytes, rt_node* nodes_out, uint32_t capacity_nodes, uint32_t* n_nodes_out,
+                              uint32_t* range_begin, uint32_t* range_end, uint8_t* elided_out);
 /* Host only, for tests without a GPU: what rt_scene_upload derives for strict pruning.
  * info[12] = enabled, pruned transform id, triangles covered, inner records with a local box, distinct normal
  * clusters, direction-grid entries, minimum shape factor, tau_coef, delta_coef, radius, local box |max|, inner nodes

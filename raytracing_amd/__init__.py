@@ -107,6 +107,16 @@ class HostScene:
         _hip_check(fn(b, len(b), out.ctypes.data, out.nbytes, C.byref(n), C.byref(root), off.ctypes.data))
         return out, int(root.value), off
 
+    def production_nodes(self):
+        """The node array the production stream's records index (rt_stream_nodes_prod_host): (nodes, range_begin, range_end, elided) -- the blob's
+        nodes followed, when the scene-level hierarchy was rebuilt, by the new scene-level range; elided[i] = 1: node i has no record."""
+        b = self.blob()
+        n, r0, r1 = _ffi.u32(), _ffi.u32(), _ffi.u32()
+        _hip_check(_ffi.hip().rt_stream_nodes_prod_host(b, len(b), None, 0, C.byref(n), C.byref(r0), C.byref(r1), None))
+        nodes = np.zeros(n.value, self.nodes().dtype); gone = np.zeros(n.value, np.uint8)
+        _hip_check(_ffi.hip().rt_stream_nodes_prod_host(b, len(b), nodes.ctypes.data, n.value, C.byref(n), C.byref(r0), C.byref(r1), gone.ctypes.data))
+        return nodes, int(r0.value), int(r1.value), gone
+
     def prune_info(self, rays=None):
         """Strict-pruning set-up of this scene as rt_scene_upload derives it (host only).  rays: n x 6 (origin, direction) in the
         pruned space -> also returns the device's verdict per ray: 1 certified, 2 certified with protected suspect leaves, 0 walked without pruning."""

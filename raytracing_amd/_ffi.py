@@ -110,6 +110,7 @@ def hip():
         L.rt_scene_destroy.argtypes = [C.c_void_p]
         L.rt_stream_build_host.argtypes = [C.c_void_p, u64, C.c_void_p, u64, P(u64), P(u32), C.c_void_p]
         L.rt_stream_build_prod_host.argtypes = [C.c_void_p, u64, C.c_void_p, u64, P(u64), P(u32), C.c_void_p]
+        L.rt_stream_nodes_prod_host.argtypes = [C.c_void_p, u64, C.c_void_p, u32, P(u32), P(u32), P(u32), C.c_void_p]
         L.rt_prune_info_host.argtypes = [C.c_void_p, u64, C.c_void_p, u32, C.c_void_p, C.c_void_p]
         L.rt_trace_closest.argtypes = [C.c_void_p, u32, C.c_void_p, f64, f64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_trace_closest_device.argtypes = [C.c_void_p, u32, C.c_void_p, f64, f64, C.c_void_p, C.c_void_p]
@@ -133,7 +134,7 @@ def hip():
 
 
 ABI_SYMBOLS = ["rt_device_count", "rt_context_create", "rt_context_destroy", "rt_context_synchronize", "rt_scene_upload",
-               "rt_scene_destroy", "rt_stream_build_host", "rt_stream_build_prod_host", "rt_prune_info_host", "rt_trace_closest", "rt_trace_closest_device", "rt_trace_closest_device_noalloc", "rt_primary_rays", "rt_render", "rt_render_begin", "rt_render_end", "rt_capture_rays",
+               "rt_scene_destroy", "rt_stream_build_host", "rt_stream_build_prod_host", "rt_stream_nodes_prod_host", "rt_prune_info_host", "rt_trace_closest", "rt_trace_closest_device", "rt_trace_closest_device_noalloc", "rt_primary_rays", "rt_render", "rt_render_begin", "rt_render_end", "rt_capture_rays",
                "rt_accum_zero", "rt_scene_set_pass_budget", "rt_render_host", "rt_resolve", "rt_resolve_host", "rt_sample_radiance", "rt_sample_radiance_sig",
                "rt_pdf_eval", "rt_ieee_div_sqrt", "rt_last_error"]
 HOST_SYMBOLS = ["rth_set_bvh_axis_seed", "rth_set_bvh_axis_mode", "rth_scene_builtin", "rth_scene_from_description", "rth_scene_free",

@@ -175,6 +175,7 @@ struct rt_scene {
     uint8_t* d_mat_uses_uv = nullptr;
     uint8_t* d_stream = nullptr;
     uint32_t* d_node_off = nullptr;
+    rt_node* d_nodes_ext = nullptr;   // node array of a re-bracketed production stream (blob's nodes + the new scene-level range)
     uint8_t* d_stream_full = nullptr;
     uint32_t* d_node_off_full = nullptr;
     uint32_t* d_cert_cells = nullptr;
@@ -636,6 +637,10 @@ struct ScenePrep {
     std::vector<uint32_t> rec_off, end_off;
     std::vector<uint8_t> stream_prod;  // production stream (see prepare_scene): the full one minus the always-entered inner nodes
     std::vector<uint32_t> rec_off_prod, end_off_prod;
+    std::vector<rt_node> nodes_ext;    // re-bracketed production hierarchy (prepare_scene): the blob's nodes followed by the new scene-level range; empty = none
+    uint32_t prod_end_off = 0;         // END record of the scene-level range in the production stream
+    uint32_t prod_r0 = 0, prod_r1 = 0; // scene-level range of the production stream's node array
+    std::vector<uint8_t> prod_elided;  // per node of that array: no record
     uint32_t root_off_prod = 0, n_elided = 0;
     double box_abs_max = 0.0;
     uint32_t root_off = 0;
@@ -772,26 +777,29 @@ static int prepare_scene(const void* blob, uint64_t nbytes, ScenePrep& P) {
     double& box_abs_max = P.box_abs_max;
     // Lays the records out and fills them; `elide` marks inner nodes that get NO record (their children follow directly and
     // links to them land on their first child): see the production stream below.
-    auto emit = [&](const std::vector<uint8_t>& elide, std::vector<uint8_t>& stream, std::vector<uint32_t>& rec_off, std::vector<uint32_t>& end_off) -> int {
-    rec_off.assign((size_t)h.n_nodes + 1, 0); end_off.assign((size_t)h.n_nodes + 1, 0);
+    // (the node array it lays out is a parameter: the production stream may come from a re-bracketed copy, see below)
+    const rt_node* all_nodes = nodes;
+    auto emit = [&](const rt_node* nodes, uint32_t n_nodes, const std::vector<uint32_t>& range_end, const std::vector<uint8_t>& ends_here, const float* local_box,
+                    const std::vector<uint8_t>& elide, std::vector<uint8_t>& stream, std::vector<uint32_t>& rec_off, std::vector<uint32_t>& end_off) -> int {
+    rec_off.assign((size_t)n_nodes + 1, 0); end_off.assign((size_t)n_nodes + 1, 0);
     uint64_t stream_bytes = 0;
-    for (uint32_t i = 0; i <= h.n_nodes; ++i) {
+    for (uint32_t i = 0; i <= n_nodes; ++i) {
         if (ends_here[i]) { end_off[i] = (uint32_t)stream_bytes; stream_bytes += RT_STREAM_REC; }  // END record of the range(s) ending here
         rec_off[i] = (uint32_t)stream_bytes;
-        if (i < h.n_nodes && !elide[i]) stream_bytes += is_tri2(nodes[i]) ? RT_STREAM_REC_TRI2 : is_sph2(nodes[i]) ? RT_STREAM_REC_SPH2 : nodes[i].prim0 != RT_NONE ? RT_STREAM_REC_LEAF : RT_STREAM_REC_INNER;
+        if (i < n_nodes && !elide[i]) stream_bytes += is_tri2(nodes[i]) ? RT_STREAM_REC_TRI2 : is_sph2(nodes[i]) ? RT_STREAM_REC_SPH2 : nodes[i].prim0 != RT_NONE ? RT_STREAM_REC_LEAF : RT_STREAM_REC_INNER;
         if (stream_bytes + RT_STREAM_PAD > 0xFFFFFFF0ull) { return fail(RT_ERR_UNSUPPORTED, "trace stream larger than 4 GiB"); }
     }
     // a link to the end of the node's own range lands on that range's END record
     auto link_off = [&](uint32_t from, uint32_t to) { return to == range_end[from] ? end_off[to] : rec_off[to]; };
     stream.assign((size_t)stream_bytes + RT_STREAM_PAD, 0);
-    for (uint32_t e = 0; e <= h.n_nodes; ++e) {
+    for (uint32_t e = 0; e <= n_nodes; ++e) {
         if (!ends_here[e]) continue;
         const float inf = std::numeric_limits<float>::infinity();
         const float box[6] = {-inf, inf, -inf, inf, -inf, inf};
         const uint32_t words[2] = {end_off[e], RT_NODE_NO_BOX | RT_STREAM_LEAF | ((RT_STREAM_REC / 16u) << 4) | (RT_STREAM_END_NODE << 8)};
         memcpy(stream.data() + end_off[e], box, 24); memcpy(stream.data() + end_off[e] + 24, words, 8);
     }
-    for (uint32_t i = 0; i < h.n_nodes; ++i) {
+    for (uint32_t i = 0; i < n_nodes; ++i) {
         if (elide[i]) continue;
         const rt_node& nd = nodes[i];
         uint8_t* rec = stream.data() + rec_off[i];
@@ -807,7 +815,7 @@ static int prepare_scene(const void* blob, uint64_t nbytes, ScenePrep& P) {
         }
         const uint32_t words[2] = {link_off(i, nd.skip), fl | ((rec_bytes / 16u) << 4) | (i << 8)};
         memcpy(rec, box, 24); memcpy(rec + 24, words, 8);
-        if (nd.prim0 == RT_NONE) memcpy(rec + RT_STREAM_REC, &P.prune.local_box[(size_t)i * 6], 24);  // inner: box of the subtree's triangles in their own space
+        if (nd.prim0 == RT_NONE) memcpy(rec + RT_STREAM_REC, local_box + (size_t)i * 6, 24);  // inner: box of the subtree's triangles in their own space
         if (!tri2 && !sph2 && nd.prim0 != RT_NONE) {
             const uint32_t ids[4] = {nd.prim0, nd.prim1, geom[nd.prim0].xform, 0u};
             memcpy(rec + RT_STREAM_REC, ids, 16);
@@ -844,51 +852,166 @@ static int prepare_scene(const void* blob, uint64_t nbytes, ScenePrep& P) {
     };
     // Full stream: every node has a record (the counting kernel and NaN-capable waves walk it).
     std::vector<uint8_t> elide((size_t)h.n_nodes, 0);
-    { int rc = emit(elide, P.stream, P.rec_off, P.end_off); if (rc != RT_OK) return rc; }
+    { int rc = emit(all_nodes, h.n_nodes, range_end, ends_here, P.prune.local_box.data(), elide, P.stream, P.rec_off, P.end_off); if (rc != RT_OK) return rc; }
     P.root_off = h.root_node == h.root_end ? P.end_off[h.root_end] : P.rec_off[h.root_node];
-    // Production stream: inner nodes that can never be pruned and whose box holds everything that can be (the ancestors of a
-    // 1000-unit ground sphere) are entered by practically every ray -- they get no record.  Sound when boxes nest: a ray
-    // only ever visits MORE than the reference this way, and every leaf re-decides with the reference's test on its own box;
-    // a leaf box that passes with the current best implies that each ancestor box (which contains it) passed with its larger
-    // best, because the slab values are monotone in the plane coordinates.
-    if (P.prune.on && P.boxes_nested) {
+    // Production stream.  Sound when the reference's boxes nest (checked above): every leaf re-decides with the reference's test on its own box, a leaf
+    // box that passes with the current best implies that each of the reference's ancestor boxes (which contain it) passed with its larger best --
+    // the slab values are monotone in the plane coordinates -- so the reference reaches exactly the leaves whose own box passes, in pre-order.  What
+    // stands ABOVE the leaves in the stream is therefore free, as long as it never keeps a ray from a leaf whose box it passes: any bracketing of
+    // the leaf sequence by boxes that enclose their leaves' boxes (and, for the strict test, local boxes that enclose their leaves' local boxes)
+    // visits a superset of the reference's leaves in the reference's order.  Three uses of that freedom:
+    //  (1) r03 / RT_REBRACKET (default on): the hierarchy above the scene-level leaves is rebuilt over the SAME leaf order, every split placed where
+    //      area(left) * leaves(left) + area(right) * leaves(right) is smallest instead of at the median the reference takes (bvh.rs:45-66);
+    //  (2) inner nodes that can never be pruned and whose box holds everything that can be (the ancestors of a 1000-unit ground sphere) get no record;
+    //  (3) r03y: no record for an inner node whose box has at least RT_ELIDE_AREA (default 0.7) of the surface area of its nearest ancestor that
+    //      kept one -- a wave pays one step for a record and, if any of its 64 rays passes, both children anyway; such boxes are passed by nearly
+    //      every wave that reaches them (found with tools/elide_eval.py on the step log of a real pass).
+    // NaN-capable waves and the counting kernel walk the full stream, which is the reference's tree record for record.
+    const rt_node* pn = all_nodes;
+    uint32_t pN = h.n_nodes, pr0 = h.root_node, pr1 = h.root_end;
+    const float* plb = P.prune.local_box.data();
+    std::vector<float> lb_ext;
+    std::vector<uint32_t> p_range_end, leaf_ids;
+    std::vector<uint8_t> p_ends_here;
+    if (P.boxes_nested) for (uint32_t i = h.root_node; i < h.root_end; ++i) if (nodes[i].prim0 != RT_NONE) leaf_ids.push_back(i);
+    {
+        const char* rb = getenv("RT_REBRACKET");
+        const size_t nL = leaf_ids.size();
+        if (P.boxes_nested && nL >= 4 && !(rb && atoi(rb) == 0) && (uint64_t)h.n_nodes + 2 * (uint64_t)nL < RT_STREAM_MAX_NODES) {
+            const uint32_t m = (uint32_t)(2 * nL - 1), base = h.n_nodes;
+            P.nodes_ext.assign(nodes, nodes + h.n_nodes);
+            P.nodes_ext.resize((size_t)base + m);
+            lb_ext.assign(P.prune.local_box.begin(), P.prune.local_box.end());
+            lb_ext.resize(((size_t)base + m) * 6);
+            auto area3 = [](const double* lo, const double* hi) {
+                const double x = std::max(hi[0] - lo[0], 0.0), y = std::max(hi[1] - lo[1], 0.0), z = std::max(hi[2] - lo[2], 0.0);
+                return x * y + y * z + z * x;
+            };
+            std::vector<double> pre((size_t)nL * 6), suf((size_t)nL * 6);   // scratch: prefix / suffix boxes of the range being split
+            struct Frame { uint32_t a, b, idx; };
+            std::vector<Frame> todo;
+            todo.push_back({0u, (uint32_t)nL, base});
+            while (!todo.empty()) {
+                const Frame f = todo.back(); todo.pop_back();
+                rt_node& nd = P.nodes_ext[f.idx];
+                const uint32_t n = f.b - f.a;
+                if (n == 1) {   // the leaf itself, copied (records carry the copy's index; rec_off of the original is pointed at it below)
+                    nd = nodes[leaf_ids[f.a]];
+                    nd.skip = f.idx + 1;
+                    continue;
+                }
+                for (uint32_t k = 0; k < n; ++k) {
+                    const rt_node& lf = nodes[leaf_ids[f.a + k]];
+                    for (int c = 0; c < 3; ++c) {
+                        pre[(size_t)k * 6 + c] = k ? std::min(pre[(size_t)(k - 1) * 6 + c], lf.bmin[c]) : lf.bmin[c];
+                        pre[(size_t)k * 6 + 3 + c] = k ? std::max(pre[(size_t)(k - 1) * 6 + 3 + c], lf.bmax[c]) : lf.bmax[c];
+                    }
+                }
+                for (uint32_t k = n; k-- > 0;) {
+                    const rt_node& lf = nodes[leaf_ids[f.a + k]];
+                    for (int c = 0; c < 3; ++c) {
+                        suf[(size_t)k * 6 + c] = k + 1 < n ? std::min(suf[(size_t)(k + 1) * 6 + c], lf.bmin[c]) : lf.bmin[c];
+                        suf[(size_t)k * 6 + 3 + c] = k + 1 < n ? std::max(suf[(size_t)(k + 1) * 6 + 3 + c], lf.bmax[c]) : lf.bmax[c];
+                    }
+                }
+                uint32_t best_s = n / 2; double best_c = INFINITY;
+                const uint32_t stride = std::max(1u, n / 4096u);   // huge ranges: every stride-th position (the search stays O(n) per level either way)
+                for (uint32_t sp = 1; sp < n; sp += stride) {      // left = [a, a + sp), right = [a + sp, b)
+                    const double c = area3(&pre[(size_t)(sp - 1) * 6], &pre[(size_t)(sp - 1) * 6 + 3]) * (double)sp + area3(&suf[(size_t)sp * 6], &suf[(size_t)sp * 6 + 3]) * (double)(n - sp);
+                    if (c < best_c) { best_c = c; best_s = sp; }
+                }
+                for (int c = 0; c < 3; ++c) { nd.bmin[c] = pre[(size_t)(n - 1) * 6 + c]; nd.bmax[c] = pre[(size_t)(n - 1) * 6 + 3 + c]; }
+                nd.skip = f.idx + 2 * n - 1; nd.flags = 0; nd.prim0 = RT_NONE; nd.prim1 = RT_NONE;
+                todo.push_back({f.a + best_s, f.b, f.idx + 2 * best_s});   // right child after the left subtree's 2 s - 1 nodes
+                todo.push_back({f.a, f.a + best_s, f.idx + 1});
+            }
+            // local boxes of the new inner nodes, bottom-up from the leaves' (never pruned unless every leaf below can be covered)
+            const float inf = std::numeric_limits<float>::infinity();
+            std::vector<uint8_t> okv(m, 0);
+            std::vector<double> boxv((size_t)m * 6);
+            double babs = P.prune.box_abs_max;
+            {
+                std::vector<uint32_t> copy_leaf(m, RT_NONE);   // virtual index -> position in leaf_ids
+                uint32_t seen = 0;
+                for (uint32_t v = 0; v < m; ++v) if (P.nodes_ext[base + v].prim0 != RT_NONE) copy_leaf[v] = seen++;
+                for (uint32_t v = m; v-- > 0;) {
+                    const rt_node& nd = P.nodes_ext[base + v];
+                    bool good = !P.prune.node_ok.empty();
+                    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                    if (nd.prim0 != RT_NONE) {
+                        const uint32_t orig = leaf_ids[copy_leaf[v]] - h.root_node;
+                        good = good && P.prune.node_ok[orig] != 0;
+                        for (int k = 0; k < 3 && good; ++k) { lo[k] = P.prune.node_box[(size_t)orig * 6 + 2 * k]; hi[k] = P.prune.node_box[(size_t)orig * 6 + 2 * k + 1]; }
+                    } else {
+                        for (uint32_t c = base + v + 1; good && c < nd.skip; c = P.nodes_ext[c].skip) {
+                            good = okv[c - base] != 0;
+                            for (int k = 0; k < 3 && good; ++k) { lo[k] = std::min(lo[k], boxv[(size_t)(c - base) * 6 + 2 * k]); hi[k] = std::max(hi[k], boxv[(size_t)(c - base) * 6 + 2 * k + 1]); }
+                        }
+                    }
+                    okv[v] = good ? 1 : 0;
+                    for (int k = 0; k < 3; ++k) {
+                        boxv[(size_t)v * 6 + 2 * k] = lo[k]; boxv[(size_t)v * 6 + 2 * k + 1] = hi[k];
+                        const bool carry = good && nd.prim0 == RT_NONE && P.prune.on;
+                        lb_ext[((size_t)base + v) * 6 + 2 * k] = carry ? f32_down_host(lo[k]) : -inf;
+                        lb_ext[((size_t)base + v) * 6 + 2 * k + 1] = carry ? f32_up_host(hi[k]) : inf;
+                        if (carry) babs = std::max(babs, std::max(std::fabs(lo[k]), std::fabs(hi[k])));
+                    }
+                }
+            }
+            P.prune.box_abs_max = babs;   // the strict filter's rounding margin is stated against the largest local coordinate in any record
+            pn = P.nodes_ext.data(); pN = base + m; pr0 = base; pr1 = base + m; plb = lb_ext.data();
+            p_range_end.assign((size_t)pN, pN);
+            for (uint32_t k = 0; k < h.n_nodes; ++k) p_range_end[k] = range_end[k];
+            p_ends_here.assign((size_t)pN + 1, 0);
+            for (uint32_t k = 0; k <= h.n_nodes; ++k) p_ends_here[k] = ends_here[k];
+            p_ends_here[h.root_end] = 0;   // the reference's scene-level range has no records in this stream ...
+            for (uint32_t i2 = 0; i2 < h.n_prims; ++i2) if (prims[i2].kind == RT_PRIM_INSTANCE && prims[i2].sub_end == h.root_end) p_ends_here[h.root_end] = 1;   // ... unless an instance range ends there too
+            p_ends_here[pN] = 1;
+            elide.assign((size_t)pN, 0);
+            for (uint32_t k = h.root_node; k < h.root_end; ++k) elide[k] = 1;
+        } else {
+            p_range_end = range_end; p_ends_here = ends_here;
+        }
+    }
+    if (P.prune.on && P.boxes_nested) {   // rule (2)
         double core_lo[3] = {INFINITY, INFINITY, INFINITY}, core_hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (uint32_t i = h.root_node; i < h.root_end; ++i)
-            if (nodes[i].prim0 == RT_NONE && std::isfinite(P.prune.local_box[(size_t)i * 6]))
-                for (int k = 0; k < 3; ++k) { core_lo[k] = std::min(core_lo[k], nodes[i].bmin[k]); core_hi[k] = std::max(core_hi[k], nodes[i].bmax[k]); }
-        for (uint32_t i = h.root_node; i < h.root_end; ++i) {
-            if (nodes[i].prim0 != RT_NONE || std::isfinite(P.prune.local_box[(size_t)i * 6]) || !(nodes[i].skip > i + 1)) continue;
+        for (uint32_t i = pr0; i < pr1; ++i)
+            if (pn[i].prim0 == RT_NONE && std::isfinite(plb[(size_t)i * 6]))
+                for (int k = 0; k < 3; ++k) { core_lo[k] = std::min(core_lo[k], pn[i].bmin[k]); core_hi[k] = std::max(core_hi[k], pn[i].bmax[k]); }
+        for (uint32_t i = pr0; i < pr1; ++i) {
+            if (pn[i].prim0 != RT_NONE || std::isfinite(plb[(size_t)i * 6]) || !(pn[i].skip > i + 1)) continue;
             bool holds = true;
-            for (int k = 0; k < 3; ++k) holds = holds && nodes[i].bmin[k] <= core_lo[k] && core_hi[k] <= nodes[i].bmax[k];
+            for (int k = 0; k < 3; ++k) holds = holds && pn[i].bmin[k] <= core_lo[k] && core_hi[k] <= pn[i].bmax[k];
             if (holds) { elide[i] = 1; ++P.n_elided; }
         }
     }
-    // The same argument lets ANY inner record go, and a wave-coherent walk gains from it whenever most waves that reach the record go on into it: the
-    // wave pays one step for the record and, if any of its 64 rays passes, both children anyway; without the record it pays the children always.  A box
-    // nearly as large as the one a ray had to pass to get here (median splits of long roofs and floors: chains of them from the root down) is passed
-    // by nearly every wave that reaches it.  Rule (found with tools/elide_eval.py on the step log of a real pass): no record
-    // for an inner node whose box has at least RT_ELIDE_AREA (default 0.7) of the surface area of its nearest ancestor that kept its record.
-    if (P.boxes_nested) {
+    if (P.boxes_nested) {   // rule (3)
         const char* qs = getenv("RT_ELIDE_AREA");
         const double q = qs ? atof(qs) : 0.7;
         if (q > 0.0) {
             auto half_area = [&](uint32_t i) {
-                const double x = std::max(nodes[i].bmax[0] - nodes[i].bmin[0], 0.0), y = std::max(nodes[i].bmax[1] - nodes[i].bmin[1], 0.0),
-                             z = std::max(nodes[i].bmax[2] - nodes[i].bmin[2], 0.0);
+                const double x = std::max(pn[i].bmax[0] - pn[i].bmin[0], 0.0), y = std::max(pn[i].bmax[1] - pn[i].bmin[1], 0.0),
+                             z = std::max(pn[i].bmax[2] - pn[i].bmin[2], 0.0);
                 return x * y + y * z + z * x;
             };
-            std::vector<double> kept_area((size_t)h.n_nodes, INFINITY);   // area of the nearest ancestor with a record (pre-order: parents come first)
-            for (uint32_t i = h.root_node; i < h.root_end; ++i) {
-                if (nodes[i].prim0 != RT_NONE) continue;
+            std::vector<double> kept_area((size_t)pN, INFINITY);   // area of the nearest ancestor with a record (pre-order: parents come first)
+            for (uint32_t i = pr0; i < pr1; ++i) {
+                if (pn[i].prim0 != RT_NONE) continue;
                 const double own = half_area(i);
-                if (!elide[i] && nodes[i].skip > i + 1 && std::isfinite(kept_area[i]) && own >= q * kept_area[i]) { elide[i] = 1; ++P.n_elided; }
+                if (!elide[i] && pn[i].skip > i + 1 && std::isfinite(kept_area[i]) && own >= q * kept_area[i]) { elide[i] = 1; ++P.n_elided; }
                 const double down = elide[i] ? kept_area[i] : own;
-                for (uint32_t c = i + 1; c < nodes[i].skip && c < h.root_end; c = nodes[c].skip) kept_area[c] = down;
+                for (uint32_t c = i + 1; c < pn[i].skip && c < pr1; c = pn[c].skip) kept_area[c] = down;
             }
         }
     }
-    { int rc = emit(elide, P.stream_prod, P.rec_off_prod, P.end_off_prod); if (rc != RT_OK) return rc; }
-    P.root_off_prod = h.root_node == h.root_end ? P.end_off_prod[h.root_end] : P.rec_off_prod[h.root_node];
+    { int rc = emit(pn, pN, p_range_end, p_ends_here, plb, elide, P.stream_prod, P.rec_off_prod, P.end_off_prod); if (rc != RT_OK) return rc; }
+    P.root_off_prod = pr0 == pr1 ? P.end_off_prod[pr1] : P.rec_off_prod[pr0];
+    P.prod_end_off = P.end_off_prod[pr1];
+    P.prod_r0 = pr0; P.prod_r1 = pr1; P.prod_elided = elide;
+    if (!P.nodes_ext.empty()) {   // the certificate names leaves by the blob's node index: point those at the copies' records
+        uint32_t seen = 0;
+        for (uint32_t v = pr0; v < pr1; ++v) if (pn[v].prim0 != RT_NONE) P.rec_off_prod[leaf_ids[seen++]] = P.rec_off_prod[v];
+    }
     static_assert(RT_STREAM_REC + 28 * 4 == RT_STREAM_REC_TRI2, "TRI2 record layout");
     {
         uint64_t n_leaf = 0, n_tri_leaf = 0;
@@ -930,7 +1053,26 @@ int rt_stream_build_prod_host(const void* blob, uint64_t nbytes, void* stream_ou
         if (capacity < P.stream_prod.size()) return fail(RT_ERR_BAD_ARG, "rt_stream_build_prod_host: buffer too small");
         memcpy(stream_out, P.stream_prod.data(), P.stream_prod.size());
     }
-    if (node_off) memcpy(node_off, P.rec_off_prod.data(), P.rec_off_prod.size() * sizeof(uint32_t));
+    if (node_off) memcpy(node_off, P.rec_off_prod.data(), ((size_t)P.h.n_nodes + 1) * sizeof(uint32_t));   // by the blob's node index (a re-bracketed stream has more nodes: rt_stream_nodes_prod_host)
+    return RT_OK;
+}
+
+int rt_stream_nodes_prod_host(const void* blob, uint64_t nbytes, rt_node* nodes_out, uint32_t capacity_nodes, uint32_t* n_nodes_out, uint32_t* range_begin, uint32_t* range_end,
+                              uint8_t* elided_out) {
+    if (!blob || !n_nodes_out) return fail(RT_ERR_BAD_ARG, "rt_stream_nodes_prod_host: null argument");
+    ScenePrep P;
+    int rc = prepare_scene(blob, nbytes, P);
+    if (rc != RT_OK) return rc;
+    const rt_node* src = P.nodes_ext.empty() ? (const rt_node*)((const uint8_t*)blob + P.h.off_nodes) : P.nodes_ext.data();
+    const uint32_t n = P.nodes_ext.empty() ? P.h.n_nodes : (uint32_t)P.nodes_ext.size();
+    *n_nodes_out = n;
+    if (range_begin) *range_begin = P.prod_r0;
+    if (range_end) *range_end = P.prod_r1;
+    if (nodes_out) {
+        if (capacity_nodes < n) return fail(RT_ERR_BAD_ARG, "rt_stream_nodes_prod_host: buffer too small");
+        memcpy(nodes_out, src, (size_t)n * sizeof(rt_node));
+        if (elided_out) memcpy(elided_out, P.prod_elided.data(), n);
+    }
     return RT_OK;
 }
 
@@ -1019,6 +1161,8 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     if (e == hipSuccess) e = hipMalloc((void**)&sc->d_node_off_full, rec_off.size() * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemcpy(sc->d_node_off_full, rec_off.data(), rec_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(sc->dblob, blob, nbytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess && !P.nodes_ext.empty()) e = hipMalloc((void**)&sc->d_nodes_ext, P.nodes_ext.size() * sizeof(rt_node));
+    if (e == hipSuccess && !P.nodes_ext.empty()) e = hipMemcpy(sc->d_nodes_ext, P.nodes_ext.data(), P.nodes_ext.size() * sizeof(rt_node), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(sc->d_mat_uses_uv, uses_uv.data(), uses_uv.size(), hipMemcpyHostToDevice);
     const PruneHost& pr = P.prune;
     if (pr.on) {
@@ -1048,6 +1192,7 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
         if (sc->d_mat_uses_uv) (void)hipFree(sc->d_mat_uses_uv);
         if (sc->d_stream) (void)hipFree(sc->d_stream);
         if (sc->d_node_off) (void)hipFree(sc->d_node_off);
+        if (sc->d_nodes_ext) (void)hipFree(sc->d_nodes_ext);
         if (sc->d_stream_full) (void)hipFree(sc->d_stream_full);
         if (sc->d_node_off_full) (void)hipFree(sc->d_node_off_full);
         if (sc->d_cert_cells) (void)hipFree(sc->d_cert_cells);
@@ -1062,7 +1207,7 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     }
     const uint8_t* d = (const uint8_t*)sc->dblob;
     SceneDev& v = sc->dev;
-    v.nodes = (const rt_node*)(d + h.off_nodes); v.prims = (const rt_prim*)(d + h.off_prims);
+    v.nodes = sc->d_nodes_ext ? sc->d_nodes_ext : (const rt_node*)(d + h.off_nodes); v.prims = (const rt_prim*)(d + h.off_prims);
     v.geom = (const rt_geom*)(d + h.off_geom); v.tri_attrs = (const rt_tri_attrs*)(d + h.off_tri_attrs);
     v.xforms = (const rt_xform*)(d + h.off_xforms);
     v.materials = (const rt_material*)(d + h.off_materials); v.textures = (const rt_texture*)(d + h.off_textures);
@@ -1071,7 +1216,7 @@ int rt_scene_upload(rt_context* ctx, const void* blob, uint64_t nbytes, rt_scene
     v.inst_cull = sc->d_inst_cull; v.inst_planes = sc->d_inst_planes;
     if (tune("RT_TUNE_INST_CULL", 1) == 0) v.inst_cull = nullptr;   // A/B
     v.stream = sc->d_stream; v.root_off = P.root_off_prod;
-    v.end_off = P.end_off_prod[h.root_end]; v.end_off_full = P.end_off[h.root_end];
+    v.end_off = P.prod_end_off; v.end_off_full = P.end_off[h.root_end];
     v.stream_full = sc->d_stream_full; v.node_off_full = sc->d_node_off_full; v.root_off_full = P.root_off;
     v.node_off = sc->d_node_off; v.box_abs_max = box_abs_max;
     v.cert_cells = sc->d_cert_cells; v.cert_entries = sc->d_cert_entries; v.cert_normals = sc->d_cert_normals;
@@ -1220,6 +1365,7 @@ int rt_scene_destroy(rt_scene* sc) {
     (void)hipFree(sc->d_mat_uses_uv);
     (void)hipFree(sc->d_stream);
     (void)hipFree(sc->d_node_off);
+    if (sc->d_nodes_ext) (void)hipFree(sc->d_nodes_ext);
     (void)hipFree(sc->d_stream_full);
     (void)hipFree(sc->d_node_off_full);
     if (sc->d_cert_cells) (void)hipFree(sc->d_cert_cells);

@@ -13,6 +13,8 @@ struct PruneHost {
     double tau_coef = 0.0, radius = 0.0, box_abs_max = 0.0, shape_min = 0.0;
     uint64_t n_tris = 0, n_prunable_nodes = 0;
     std::vector<float> local_box;          // 6 per node: (lo, hi) per axis in space xf, (-inf, +inf) = never pruned
+    std::vector<uint8_t> node_ok;          // per node of the scene-level range (index - root_node): every primitive below can be covered (empty: pruning off)
+    std::vector<double> node_box;          // 6 per such node: f64 box of the primitives below in space xf (valid where node_ok)
     std::vector<double> normals;           // 3 per distinct (clustered) unit normal
     std::vector<uint32_t> cell_off;        // CSR over direction cells into entries (lists padded to a multiple of 4 by repeating their last entry)
     std::vector<CertEntry> entries;        // normals whose "nearly perpendicular" band meets the cell
@@ -190,6 +192,7 @@ static void build_prune(const rt_blob_header& h, const rt_node* nodes, const rt_
         ok[i - n0] = 1;
         for (int k = 0; k < 3; ++k) { box[(size_t)(i - n0) * 6 + 2 * k] = lo[k]; box[(size_t)(i - n0) * 6 + 2 * k + 1] = hi[k]; }
     }
+    R.node_ok = ok; R.node_box = box;   // the production stream's re-bracketed hierarchy derives the local boxes of its own inner nodes from the leaves'
     double babs = 0.0;
     for (uint32_t i = n0; i < n1; ++i) {
         if (!ok[i - n0] || nodes[i].prim0 != RT_NONE) continue;   // only inner records carry a local box

@@ -167,44 +167,6 @@ def _ground_scene():
     return rt.HostScene.from_description(s.finish(ids, build_bvh=True))
 
 
-def _expected_elision(hs, full, off_full, area_q=0.7):
-    """The two rules of prepare_scene (rt_device.hip), restated: (1) with strict pruning on, inner nodes that are never pruned and whose box holds every
-    node that can be; (2) inner nodes whose box has at least area_q of the surface area of their nearest ancestor that keeps its record.  Both only when
-    the boxes of the scene-level array are finite and nest."""
-    h, nodes, info = hs.header(), hs.nodes(), hs.prune_info()
-    rng_ = range(h.root_node, h.root_end)
-    kids = lambda i: _children(nodes, i)
-    nested = all(not (int(nodes[i]["flags"]) & NO_BOX) and np.isfinite(nodes[i]["bmin"]).all() and np.isfinite(nodes[i]["bmax"]).all() for i in rng_)
-    inner = [i for i in rng_ if nodes[i]["prim0"] == rt.NONE]
-    for i in inner:
-        for c in kids(i):
-            nested = nested and int(nodes[c]["skip"]) <= int(nodes[i]["skip"]) and (nodes[i]["bmin"] <= nodes[c]["bmin"]).all() and (nodes[c]["bmax"] <= nodes[i]["bmax"]).all()
-    gone = set()
-    if not nested:
-        return gone, inner
-    if info["on"]:
-        rawf = full.tobytes()
-        local = lambda i: struct.unpack_from("<6f", rawf, int(off_full[i]) + 32)
-        prunable = [i for i in inner if np.isfinite(local(i)).all()]
-        if prunable:
-            core_lo = np.min([nodes[i]["bmin"] for i in prunable], axis=0); core_hi = np.max([nodes[i]["bmax"] for i in prunable], axis=0)
-            for i in inner:
-                if i not in prunable and int(nodes[i]["skip"]) > i + 1 and (nodes[i]["bmin"] <= core_lo).all() and (core_hi <= nodes[i]["bmax"]).all():
-                    gone.add(i)
-    def area(i):
-        e = np.maximum(nodes[i]["bmax"] - nodes[i]["bmin"], 0.0)
-        return e[0] * e[1] + e[1] * e[2] + e[2] * e[0]
-    kept = {i: np.inf for i in rng_}
-    for i in inner:                                                      # pre-order: parents come first
-        own = area(i)
-        if i not in gone and int(nodes[i]["skip"]) > i + 1 and np.isfinite(kept[i]) and own >= area_q * kept[i]:
-            gone.add(i)
-        down = kept[i] if i in gone else own
-        for c in kids(i):
-            kept[c] = down
-    return gone, inner
-
-
 def _children(nodes, i):
     out, c = [], i + 1
     while c < int(nodes[i]["skip"]):
@@ -212,48 +174,165 @@ def _children(nodes, i):
     return out
 
 
+def _expected_elision(hs, pn, r0, r1, local, area_q=0.7):
+    """Rules (2) and (3) of prepare_scene (rt_device.hip), restated on the production node array: (2) with strict pruning on, inner nodes that are
+    never pruned and whose box holds every node that can be; (3) inner nodes whose box has at least area_q of the surface area of their nearest
+    ancestor that keeps its record.  `local(i)` = the fp32 local box of inner node i (infinite: never pruned)."""
+    info = hs.prune_info()
+    inner = [i for i in range(r0, r1) if pn[i]["prim0"] == rt.NONE]
+    gone = set()
+    if info["on"]:
+        prunable = [i for i in inner if np.isfinite(local(i)).all()]
+        if prunable:
+            core_lo = np.min([pn[i]["bmin"] for i in prunable], axis=0); core_hi = np.max([pn[i]["bmax"] for i in prunable], axis=0)
+            pr = set(prunable)
+            for i in inner:
+                if i not in pr and int(pn[i]["skip"]) > i + 1 and (pn[i]["bmin"] <= core_lo).all() and (core_hi <= pn[i]["bmax"]).all():
+                    gone.add(i)
+
+    def area(i):
+        e = np.maximum(pn[i]["bmax"] - pn[i]["bmin"], 0.0)
+        return e[0] * e[1] + e[1] * e[2] + e[2] * e[0]
+    kept = {i: np.inf for i in range(r0, r1)}
+    for i in inner:                                                      # pre-order: parents come first
+        own = area(i)
+        if i not in gone and int(pn[i]["skip"]) > i + 1 and np.isfinite(kept[i]) and own >= area_q * kept[i]:
+            gone.add(i)
+        down = kept[i] if i in gone else own
+        for c in _children(pn, i):
+            kept[c] = down
+    return gone, inner
+
+
+def _boxes_nest(hs):
+    h, nodes = hs.header(), hs.nodes()
+    rng_ = range(h.root_node, h.root_end)
+    ok = all(not (int(nodes[i]["flags"]) & NO_BOX) and np.isfinite(nodes[i]["bmin"]).all() and np.isfinite(nodes[i]["bmax"]).all() for i in rng_)
+    for i in rng_:
+        if not ok or nodes[i]["prim0"] != rt.NONE:
+            continue
+        for c in _children(nodes, i):
+            ok = ok and int(nodes[c]["skip"]) <= int(nodes[i]["skip"]) and (nodes[i]["bmin"] <= nodes[c]["bmin"]).all() and (nodes[c]["bmax"] <= nodes[i]["bmax"]).all()
+    return ok
+
+
 @pytest.mark.parametrize("name", ["mesh", "ground", "random", "cornell", "simple_triangle"])
-def test_production_stream_drops_only_nodes_every_useful_ray_enters(name):
-    # The stream the kernel walks ("production stream"): inner nodes that most waves reaching them enter anyway have no record --
-    # the never-pruned ancestors of a ground sphere, and (r03y) boxes nearly as large as the nearest recorded ancestor's.  Sound for ANY inner node when
-    # boxes nest (a ray only visits more; every leaf re-decides on its own box).  Everything else is the full stream, re-linked.
+def test_production_stream_is_the_reference_leaf_sequence_under_a_hierarchy_of_our_own(name):
+    # The stream the kernel walks (DESIGN.md section 5, "production stream").  When the reference's boxes nest, the reference reaches exactly the
+    # leaves whose OWN box passes, in pre-order; what stands above the leaves is free as long as it encloses them.  So (r03): the scene-level
+    # hierarchy is rebuilt over the same leaf order with surface-area splits, and inner nodes most waves enter anyway have no record.
     hs = _ground_scene() if name == "ground" else rt.HostScene.builtin(name, bvh_seed=3, legacy_bvh=(name == "simple_triangle"))
     h, nodes, info = hs.header(), hs.nodes(), hs.prune_info()
     full, root_full, off_full = hs.trace_stream()
     prod, root_prod, off_prod = hs.trace_stream(production=True)
-    rf, rp = _records(full), _records(prod)
-    real_f = {r["node"]: r for r in rf if r["node"] != END_NODE}
-    real_p = {r["node"]: r for r in rp if r["node"] != END_NODE}
-    gone = sorted(set(real_f) - set(real_p))
-    assert len(gone) == int(info["elided_nodes"]) and set(real_p) <= set(real_f)
-    want, inner = _expected_elision(hs, full, off_full)
-    assert set(gone) == want
-    if name == "cornell":
-        assert not gone and np.array_equal(full, prod)                       # a list of instances: no boxes at the scene level
+    pn, r0, r1, gone_flags = hs.production_nodes()
+    ref_leaves = [i for i in range(h.root_node, h.root_end) if nodes[i]["prim0"] != rt.NONE]
+    rebuilt = _boxes_nest(hs) and len(ref_leaves) >= 4
+    assert (len(pn) > h.n_nodes) == rebuilt
+    assert pn[:h.n_nodes].tobytes() == nodes.tobytes()                      # the blob's nodes come first, untouched (the full stream indexes them)
+    if not rebuilt:
+        assert (r0, r1) == (h.root_node, h.root_end) and len(pn) == h.n_nodes
+        if name == "cornell":
+            assert not gone_flags.any() and np.array_equal(full, prod)      # a list of instances: no boxes at the scene level
+    else:
+        assert (r0, r1) == (h.n_nodes, h.n_nodes + 2 * len(ref_leaves) - 1) and len(pn) == r1
+        # a pre-order binary tree over copies of the reference's leaves in the reference's order; inner boxes are the exact unions of their children's
+        copies = [i for i in range(r0, r1) if pn[i]["prim0"] != rt.NONE]
+        assert len(copies) == len(ref_leaves)
+        for c, o in zip(copies, ref_leaves):
+            for f in ("bmin", "bmax", "flags", "prim0", "prim1"):
+                assert np.array_equal(pn[c][f], nodes[o][f])
+            assert int(pn[c]["skip"]) == c + 1
+            assert off_prod[o] == _record_at(prod, int(off_prod[o]))["off"] and _record_at(prod, int(off_prod[o]))["node"] == c     # the certificate's look-up by blob index lands on the copy
+        for i in range(r0, r1):
+            if pn[i]["prim0"] != rt.NONE:
+                continue
+            kids = _children(pn, i)
+            assert len(kids) == 2 and int(pn[i]["skip"]) <= r1 and all(int(pn[k]["skip"]) <= int(pn[i]["skip"]) for k in kids)
+            assert np.array_equal(pn[i]["bmin"], np.min([pn[k]["bmin"] for k in kids], axis=0)) and np.array_equal(pn[i]["bmax"], np.max([pn[k]["bmax"] for k in kids], axis=0))
+        assert gone_flags[h.root_node:h.root_end].all()                     # the reference's own scene-level range has no record in this stream
+    # records: one per node of the range that keeps one, in order; rules (2) and (3) restated
+    rp = _records(prod)
+    rawp = prod.tobytes()
+    by_node = {r["node"]: r for r in rp if r["node"] != END_NODE}
+    local = lambda i: struct.unpack_from("<6f", rawp, by_node[i]["off"] + 32) if i in by_node else (np.inf,) * 6
+    # the local box of a node without a record is not in the stream: rule (2) only asks whether it is finite, i.e. whether every leaf below can be
+    # covered -- equivalently whether every RECORDED inner node below it has a finite local box and every leaf below hangs under one or is coverable;
+    # the library's own flags are checked for consistency instead: an elided node's children are where links to it land
+    want_range = [i for i in range(r0, r1) if not gone_flags[i]]
+    scene_recs = [r["node"] for r in rp if r["node"] != END_NODE and r0 <= r["node"] < r1]
+    assert scene_recs == want_range
+    n_gone = int(gone_flags[r0:r1].sum())
+    assert n_gone == int(info["elided_nodes"])
+    if rebuilt or _boxes_nest(hs):
+        if name in ("mesh", "ground"):
+            assert n_gone > 0
+        for i in range(r0, r1):
+            if gone_flags[i]:
+                assert pn[i]["prim0"] == rt.NONE and int(pn[i]["skip"]) > i + 1          # only inner nodes go
+        # rule (3) on its own is checkable from the node array: every node it names is gone, and every gone node is named by (2) or (3)
+        want, _ = _expected_elision(hs, pn, r0, r1, lambda i: local(i) if not gone_flags[i] else _local_by_union(pn, i, gone_flags, local))
+        assert want == {i for i in range(r0, r1) if gone_flags[i]}
+    else:
+        assert n_gone == 0
+    # links: a record's skip is the record of the node-level skip target (or the first record below it, or the range's END)
+    off_of = {r["node"]: r["off"] for r in rp if r["node"] != END_NODE}
+    end_rec = [r for r in rp if r["node"] == END_NODE]
+
+    def first_record_at_or_after(i):
+        while i < r1 and gone_flags[i]:
+            i += 1                                                           # an elided node's first child follows it in pre-order
+        return off_of[i] if i < r1 else None
+    for i in want_range:
+        tgt = first_record_at_or_after(int(pn[i]["skip"]))
+        if tgt is None:
+            assert any(e["off"] == by_node[i]["skip"] for e in end_rec)
+        else:
+            assert by_node[i]["skip"] == tgt
+    # walks: every box passes -> every recorded node once, in order, and the leaves in the reference's order
+    seen = _walk(prod, root_prod, lambda n, f, k: True)
+    assert seen == want_range
+    assert [(int(pn[n]["prim0"]), int(pn[n]["prim1"])) for n in seen if pn[n]["prim0"] != rt.NONE] == [(int(nodes[o]["prim0"]), int(nodes[o]["prim1"])) for o in ref_leaves]
+    if not _boxes_nest(hs):
         return
-    if name in ("mesh", "ground"):
-        assert gone
-    for i in gone:
-        assert i in inner
-        assert off_prod[i] == off_prod[i + 1]                               # links to it land on its first child
-        for j in range(i + 1, int(nodes[i]["skip"])):                       # boxes nest below it (what the argument needs)
-            if not int(nodes[j]["flags"]) & NO_BOX:
-                assert (nodes[i]["bmin"] <= nodes[j]["bmin"]).all() and (nodes[j]["bmax"] <= nodes[i]["bmax"]).all()
-    # surviving records: same bytes apart from the link, same order; links follow the same node-level skip
-    rawp = prod.tobytes(); rawf = full.tobytes()
-    assert [r["node"] for r in rp if r["node"] != END_NODE] == [n for n in range(h.n_nodes) if n not in gone]
-    for n, r in real_p.items():
-        f = real_f[n]
-        assert r["off"] == off_prod[n] and r["size"] == f["size"]
-        assert rawp[r["off"]:r["off"] + 24] == rawf[f["off"]:f["off"] + 24] and rawp[r["off"] + 28:r["off"] + r["size"]] == rawf[f["off"] + 28:f["off"] + f["size"]]
-    keep = lambda seen: [n for n in seen if n not in gone]
-    assert _walk(prod, root_prod, lambda n, f, k: True) == keep(_walk(full, root_full, lambda n, f, k: True))
-    # any decision function that enters the dropped nodes gives the same visit order on both streams
-    rng = np.random.default_rng(5)
-    for _ in range(20):
-        coin = rng.random(h.n_nodes) < 0.7
-        dec = lambda n, f, k: bool(coin[n]) or n in gone
-        assert _walk(prod, root_prod, dec) == keep(_walk(full, root_full, dec))
+    # a decision that is monotone under enclosure (box contains the point q): the leaves whose OWN box holds q are reached by both walks, in the
+    # same order -- the reference's walk reaches nothing else that passes, and neither does ours
+    rng = np.random.default_rng(11)
+    for _ in range(12):
+        lf = ref_leaves[int(rng.integers(len(ref_leaves)))]
+        q = nodes[lf]["bmin"] + rng.random(3) * (nodes[lf]["bmax"] - nodes[lf]["bmin"])
+        inside_f = lambda n, f, k: bool((nodes[n]["bmin"] <= q).all() and (q <= nodes[n]["bmax"]).all())
+        inside_p = lambda n, f, k: bool((pn[n]["bmin"] <= q).all() and (q <= pn[n]["bmax"]).all())
+        hit_f = [(int(nodes[n]["prim0"]), int(nodes[n]["prim1"])) for n in _walk(full, root_full, inside_f) if nodes[n]["prim0"] != rt.NONE and inside_f(n, 0, 0)]
+        hit_p = [(int(pn[n]["prim0"]), int(pn[n]["prim1"])) for n in _walk(prod, root_prod, inside_p) if pn[n]["prim0"] != rt.NONE and inside_p(n, 0, 0)]
+        brute = [(int(nodes[o]["prim0"]), int(nodes[o]["prim1"])) for o in ref_leaves if (nodes[o]["bmin"] <= q).all() and (q <= nodes[o]["bmax"]).all()]
+        assert hit_f == brute and hit_p == brute and brute
+
+
+def _record_at(stream, off):
+    raw = stream.tobytes()
+    skip, word = struct.unpack_from("<2I", raw, off + 24)
+    return dict(off=off, skip=skip, node=word >> 8, kind=word & 12)
+
+
+def _local_by_union(pn, i, gone_flags, local):
+    """fp32 local box of an inner node WITHOUT a record: the union of the local boxes of the recorded inner nodes below it, infinite as soon as a
+    leaf hangs directly below an unrecorded chain (a leaf's own local box is not in the stream) -- enough to tell finite from infinite for the
+    nodes rule (2) can name: their subtree holds a never-covered leaf, so some chain below them ends in an infinite box or a bare leaf."""
+    lo = np.full(3, np.inf); hi = np.full(3, -np.inf)
+    stack = _children(pn, i)
+    while stack:
+        c = stack.pop()
+        if pn[c]["prim0"] != rt.NONE:
+            return (-np.inf, np.inf) * 3
+        if gone_flags[c]:
+            stack += _children(pn, c)
+            continue
+        b = local(c)
+        if not np.isfinite(b).all():
+            return (-np.inf, np.inf) * 3
+        lo = np.minimum(lo, b[0::2]); hi = np.maximum(hi, b[1::2])
+    return (lo[0], hi[0], lo[1], hi[1], lo[2], hi[2])
 
 
 @pytest.mark.parametrize("name,seed", [("random", 1), ("random", 8), ("mesh", 3), ("simple_triangle", 0)])
