@@ -256,6 +256,7 @@ extern "C" {
     pub fn rt_scene_destroy(scene: *mut rt_scene) -> c_int;
     pub fn rt_stream_build_host(blob: *const c_void, nbytes: u64, stream_out: *mut c_void, capacity: u64, stream_bytes: *mut u64, root_off: *mut u32, node_off: *mut u32) -> c_int;
     pub fn rt_stream_build_prod_host(blob: *const c_void, nbytes: u64, stream_out: *mut c_void, capacity: u64, stream_bytes: *mut u64, root_off: *mut u32, node_off: *mut u32) -> c_int;
+    pub fn rt_stream_nodes_prod_host(blob: *const c_void, nbytes: u64, nodes_out: *mut rt_node, capacity_nodes: u32, n_nodes_out: *mut u32, range_begin: *mut u32, range_end: *mut u32, elided_out: *mut u8) -> c_int;
     pub fn rt_prune_info_host(blob: *const c_void, nbytes: u64, info: *mut f64, n_rays: u32, rays: *const f64, certified: *mut u8) -> c_int;
     pub fn rt_trace_closest(scene: *mut rt_scene, n: u32, rays: *const f64, t_min: f64, t_max: f64, prim_id: *mut u32, inst_id: *mut u32, t: *mut f64, counters: *mut u64) -> c_int;
     pub fn rt_trace_closest_device(scene: *mut rt_scene, n: u32, rays_dev: *const f64, t_min: f64, t_max: f64, prim_id_dev: *mut u32, t_dev: *mut f64) -> c_int;
