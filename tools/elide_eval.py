@@ -62,7 +62,7 @@ def main():
     leaves_under = np.zeros(n, np.int64)
     for i in range(n - 1, -1, -1):
         leaves_under[i] = 1 if kinds[i] != 0 else sum(leaves_under[c] for c in children[i])
-    nd = hs.nodes()
+    nd = hs.production_nodes()[0]     # the array the production stream's node words index (the blob's nodes + a re-bracketed scene-level range)
     ext = np.maximum(nd["bmax"][nodes] - nd["bmin"][nodes], 0.0)
     area = ext[:, 0] * ext[:, 1] + ext[:, 1] * ext[:, 2] + ext[:, 2] * ext[:, 0]
     print(f"production stream: {n} records, {int((kinds == 0).sum())} inner, {int((kinds != 0).sum())} leaves, LEAF_COST {LEAF_COST}")
