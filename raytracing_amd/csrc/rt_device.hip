@@ -889,6 +889,7 @@ static int prepare_scene(const void* blob, uint64_t nbytes, ScenePrep& P) {
             };
             std::vector<double> pre((size_t)nL * 6), suf((size_t)nL * 6);   // scratch: prefix / suffix boxes of the range being split
             struct Frame { uint32_t a, b, idx; };
+            uint64_t sweep_work = 0;
             std::vector<Frame> todo;
             todo.push_back({0u, (uint32_t)nL, base});
             while (!todo.empty()) {
@@ -916,7 +917,11 @@ static int prepare_scene(const void* blob, uint64_t nbytes, ScenePrep& P) {
                 }
                 uint32_t best_s = n / 2; double best_c = INFINITY;
                 const uint32_t stride = std::max(1u, n / 4096u);   // huge ranges: every stride-th position (the search stays O(n) per level either way)
-                for (uint32_t sp = 1; sp < n; sp += stride) {      // left = [a, a + sp), right = [a + sp, b)
+                // one-sided splits make the tree deep and this loop O(n) per level: once the sweeps have cost 256 passes over the leaves, the rest of the
+                // tree takes the median (what the reference does; the boxes above are still the unions)
+                sweep_work += n;
+                const bool search = sweep_work <= 256ull * (uint64_t)nL;
+                for (uint32_t sp = 1; search && sp < n; sp += stride) {      // left = [a, a + sp), right = [a + sp, b)
                     const double c = area3(&pre[(size_t)(sp - 1) * 6], &pre[(size_t)(sp - 1) * 6 + 3]) * (double)sp + area3(&suf[(size_t)sp * 6], &suf[(size_t)sp * 6 + 3]) * (double)(n - sp);
                     if (c < best_c) { best_c = c; best_s = sp; }
                 }
