@@ -166,6 +166,29 @@ def test_sorted_bounce_queues_give_the_frame_of_unsorted_ones(gpu_ctx, name, int
     gs.close()
 
 
+@pytest.mark.parametrize("name,integ,w,h,spp", [("mesh", rt.INT_MIS, 320, 180, 4), ("random", rt.INT_MIS, 200, 112, 8), ("random_blur", rt.INT_BRDF, 160, 90, 4)])
+def test_production_hierarchy_gives_the_frame_of_the_reference_tree(gpu_ctx, monkeypatch, name, integ, w, h, spp):
+    # The stream the kernel walks holds the reference's leaves in the reference's order under a hierarchy of the library's own (re-bracketed by surface
+    # area, inner records most waves enter anyway left out: DESIGN.md section 5).  Every hit and tie is decided at a leaf, so the frame -- and every
+    # closest hit -- is the one the reference's own tree gives: RT_REBRACKET=0 RT_ELIDE_AREA=0 (read at upload) walks that tree record for record.
+    hs, _ = _pair(name)
+    rays = gpu_ctx.upload(hs)
+    a, sa = rays.render_host(w, h, 0, spp, 5, integ, seed=33)
+    pr = rays.primary_rays(96, 54, 0, 0x5EED)
+    pa, ia, ta = rays.trace_closest(pr, 0.001, 1e30)
+    rays.close()
+    monkeypatch.setenv("RT_REBRACKET", "0"); monkeypatch.setenv("RT_ELIDE_AREA", "0")
+    ref = gpu_ctx.upload(hs)
+    b, sb = ref.render_host(w, h, 0, spp, 5, integ, seed=33)
+    pb, ib, tb = ref.trace_closest(pr, 0.001, 1e30)
+    ref.close()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert sa.rays == sb.rays and sa.paths == sb.paths == w * h * spp
+    assert np.array_equal(pa, pb) and np.array_equal(ia, ib) and np.array_equal(ta.view(np.uint64), tb.view(np.uint64))
+    if name == "mesh":
+        assert sa.trace_wave_steps == 0 or sb.trace_wave_steps == 0 or sa.trace_wave_steps < sb.trace_wave_steps
+
+
 @pytest.mark.parametrize("name,integ,depth", [("random", rt.INT_MIS, 12), ("simple", rt.INT_BRDF, 6), ("sphere", rt.INT_LIGHT_IS, 5)])
 def test_material_binned_shading_gives_the_frame_of_queue_order(gpu_ctx, name, integ, depth):
     # opt-in RT_RENDER_MATERIAL_BINS: before every shade launch the queue's slots are regrouped by the material class of their hits
