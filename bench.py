@@ -203,6 +203,10 @@ class HipRenderer:
         self.ctx = rt.Context(local_rank)
         self.gs = self.ctx.upload(blob)
         self.flags = rt.RENDER_ONE_LANE if args.one_lane else 0
+        import ctypes
+        n_lights = rt._ffi.BlobHeader.from_buffer_copy(bytes(blob[:ctypes.sizeof(rt._ffi.BlobHeader)])).n_lights
+        # no light sample can occur (run_paths in rt_device.hip): 32-byte bounce records, and a records buffer sized for them
+        self.compact_records = not (self.integrator == rt.INT_MIS and n_lights > 0)
 
     def render(self, accum, b, e, flags=0, samples_per_pass=0):
         return self.gs.render(accum.data_ptr(), self.W, self.H, b, e, self.depth, self.integrator, seed=0x5EED, samples_per_pass=samples_per_pass,
@@ -216,14 +220,14 @@ class HipRenderer:
     LANE_BYTES = 112 << 30   # path state per lane: two lanes + scene + certificate tables stay under the 288 GB
 
     def bytes_per_sample(self):
-        return self.W * self.H * (self.depth * 96 + 320)     # depth x 96 B of bounce records + 320 B per path
+        return self.W * self.H * (self.depth * (32 if self.compact_records else 96) + 320)     # depth x 96 (or 32) B of bounce records + 320 B per path
 
     def pass_size_for(self, n_spp):
         """A job of n_spp samples runs as ONE pass when its path state fits LANE_BYTES; otherwise the library's default pass size (0)."""
         return n_spp if n_spp * self.bytes_per_sample() <= self.LANE_BYTES and n_spp * self.W * self.H < 0x7FFFFF00 else 0
 
     def max_job_spp(self):
-        """The largest job that still runs as one pass per lane (1080p, depth 5: 72 spp)."""
+        """The largest job that still runs as one pass per lane (1080p, depth 5: 72 spp with full MIS records, 120 with compact ones)."""
         return max(1, min(self.LANE_BYTES // self.bytes_per_sample(), (0x7FFFFF00 - 1) // (self.W * self.H)))
 
     def end(self, job):

@@ -159,6 +159,7 @@ struct Workspace {
     uint32_t* raw_queue = nullptr; uint32_t* raw_keys = nullptr; uint32_t* raw_squeue = nullptr; uint32_t* raw_skeys = nullptr; uint32_t* sorted_keys = nullptr;  // ray sorting
     void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     uint32_t cap = 0; int32_t depth = 0;
+    uint32_t rec_stride = 0;        // doubles per bounce record the records buffer was sized for (REC_STRIDE, or CREC_STRIDE for calls that can only write compact records)
     uint32_t* order = nullptr;      // material-binned shading order of the current queue (k_bin_scatter)
     uint8_t* cls = nullptr;         // class byte per queue slot (k_bin_count)
     uint32_t* bins = nullptr;       // [class][unit] counts, then their exclusive prefix (k_bin_count / k_bin_scan)
@@ -233,10 +234,13 @@ template <class T> static int ws_alloc(Workspace& ws, T*& out, size_t count) {
     out = (T*)p;
     return RT_OK;
 }
-static int ws_ensure(rt_scene* sc, Workspace& ws, uint32_t cap, int32_t depth);
+// compact: the call can only write 32-byte bounce records (no light sample can occur: run_paths) -- its records buffer is a third of the full one, so a
+// pass of such a call may hold more samples in the same memory (bench.py sizes its jobs by that)
+static int ws_ensure(rt_scene* sc, Workspace& ws, uint32_t cap, int32_t depth, bool compact = false);
 static int ws_ensure(rt_scene* sc, uint32_t cap, int32_t depth) { return ws_ensure(sc, sc->ws, cap, depth); }
-static int ws_ensure(rt_scene* sc, Workspace& ws, uint32_t cap, int32_t depth) {
-    if (ws.cap >= cap && ws.depth >= depth) return RT_OK;
+static int ws_ensure(rt_scene* sc, Workspace& ws, uint32_t cap, int32_t depth, bool compact) {
+    const uint32_t rec_stride = compact ? (uint32_t)CREC_STRIDE : (uint32_t)REC_STRIDE;
+    if (ws.cap >= cap && ws.depth >= depth && ws.rec_stride >= rec_stride) return RT_OK;
     ws_free(ws);
     cap = (cap + 255u) & ~255u;
     int rc;
@@ -245,7 +249,7 @@ static int ws_ensure(rt_scene* sc, Workspace& ws, uint32_t cap, int32_t depth) {
     WS(ws.pb.hit_prim, cap) WS(ws.pb.hit_inst, cap) WS(ws.pb.hit_t, cap)
     WS(ws.pb.hit, cap) WS(ws.pb.info, cap)
     WS(ws.pb.terminal, 4 * (size_t)cap) WS(ws.pb.radiance, 3 * (size_t)cap)
-    WS(ws.pb.records, (size_t)std::max(depth, 1) * REC_STRIDE * cap)
+    WS(ws.pb.records, (size_t)std::max(depth, 1) * rec_stride * cap)
     WS(ws.queue[0], cap) WS(ws.queue[1], cap) WS(ws.shadow_queue, cap) WS(ws.counts, 2 * ((size_t)std::max(depth, 1) + 2)) WS(ws.stats, RT_N_STATS)
     WS(ws.in_pixel, cap) WS(ws.in_sample, cap)
     WS(ws.raw_queue, cap) WS(ws.raw_keys, cap) WS(ws.raw_squeue, cap) WS(ws.raw_skeys, cap) WS(ws.sorted_keys, cap)
@@ -262,7 +266,7 @@ static int ws_ensure(rt_scene* sc, Workspace& ws, uint32_t cap, int32_t depth) {
     for (auto& e : ws.lag_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; ws_free(ws); return fail(RT_ERR_HIP, "event creation failed"); }
     if (hipStreamCreateWithFlags(&ws.side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ws.ev_shaded, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ws.ev_shadowed, hipEventDisableTiming) != hipSuccess) { ws_free(ws); return fail(RT_ERR_HIP, "side stream creation failed"); }
-    ws.pb.cap = cap; ws.cap = cap; ws.depth = depth;
+    ws.pb.cap = cap; ws.cap = cap; ws.depth = depth; ws.rec_stride = rec_stride;
     return RT_OK;
 }
 
@@ -1483,14 +1487,14 @@ static uint32_t default_pass_size(uint32_t npix, int32_t max_depth, uint64_t bud
 // occupies in part), the scene's budget is halved -- 80, 40, 20, 10, 5, 2.5 GiB: a fixed ladder -- and the pass size recomputed,
 // so the call renders in smaller passes instead of failing; the budget stays lowered for the scene's later calls (they cut the
 // same passes) and rt_stats.samples_per_pass reports what was used.  `halve_call`: rt_render's "at most half the call's samples".
-static int ws_ensure_default(rt_scene* sc, Workspace& ws, uint32_t npix, int32_t max_depth, uint32_t spp, bool halve_call, uint32_t& spass) {
+static int ws_ensure_default(rt_scene* sc, Workspace& ws, uint32_t npix, int32_t max_depth, uint32_t spp, bool halve_call, uint32_t& spass, bool compact) {
     for (int step = 0;; ++step) {
         spass = default_pass_size(npix, max_depth, sc->pass_budget);
         if (halve_call) spass = std::min(spass, (spp + 1u) / 2u);
         spass = std::max(1u, std::min(spass, spp));
         spass = (spp + (spp + spass - 1u) / spass - 1u) / ((spp + spass - 1u) / spass);   // the same number of passes, of near-equal size (25 spp at 12 per pass: 9 + 8 + 8, not 12 + 12 + 1)
         if ((uint64_t)npix * spass > 0x7FFFFF00ull) return fail(RT_ERR_BAD_ARG, "samples_per_pass * pixels too large");
-        int rc = ws_ensure(sc, ws, npix * spass, max_depth);
+        int rc = ws_ensure(sc, ws, npix * spass, max_depth, compact);
         if (rc != RT_ERR_OOM || step >= 5 || default_pass_size(npix, max_depth, sc->pass_budget) == 1) return rc;
         (void)hipGetLastError();
         sc->pass_budget /= 2;
@@ -1546,13 +1550,14 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
     // samples so that both lanes have work.  If the buffers do not fit (a shared GPU), the budget steps down its ladder
     // (ws_ensure_default) and the call renders in smaller passes; rt_stats.samples_per_pass says which.
     uint32_t spass = p->samples_per_pass;
+    const bool compact = !(p->integrator == RT_INT_MIS && sc->dev.n_lights > 0);   // as run_paths decides it
     if (spass == 0) {
-        rc = ws_ensure_default(sc, sc->ws, npix, p->max_depth, spp, true, spass);
+        rc = ws_ensure_default(sc, sc->ws, npix, p->max_depth, spp, true, spass, compact);
         if (rc != RT_OK) return rc;
     } else {
         spass = std::max(1u, std::min(spass, spp));
         if ((uint64_t)npix * spass > 0x7FFFFF00ull) return fail(RT_ERR_BAD_ARG, "samples_per_pass * pixels too large");
-        rc = ws_ensure(sc, sc->ws, npix * spass, p->max_depth);
+        rc = ws_ensure(sc, sc->ws, npix * spass, p->max_depth, compact);
         if (rc != RT_OK) return rc;
     }
     const bool count_tests = (p->flags & RT_RENDER_COUNT_TESTS) != 0;
@@ -1562,7 +1567,7 @@ int rt_render(rt_scene* sc, const rt_render_params* p, float* accum_dev, rt_stat
     hipStream_t st = sc->ctx->stream;
     if (n_lanes == 2 && !sc->stream2) HIP_OK(hipStreamCreateWithFlags(&sc->stream2, hipStreamNonBlocking));
     if (n_lanes == 2 && (uint64_t)npix * spass >= sc->ws2_failed_cap) n_lanes = 1;      // did not fit before
-    if (n_lanes == 2 && ws_ensure(sc, sc->ws2, npix * spass, p->max_depth) != RT_OK) {  // no room for a second set of path buffers:
+    if (n_lanes == 2 && ws_ensure(sc, sc->ws2, npix * spass, p->max_depth, compact) != RT_OK) {  // no room for a second set of path buffers:
         (void)hipGetLastError();                                                         // same passes, one after the other
         sc->ws2_failed_cap = (uint64_t)npix * spass;
         n_lanes = 1;
@@ -1754,11 +1759,12 @@ int rt_render_begin(rt_scene* sc, const rt_render_params* p, float* accum_dev, r
     if (lane == 1 && !sc->stream2) HIP_OK(hipStreamCreateWithFlags(&sc->stream2, hipStreamNonBlocking));
     for (auto& e : sc->job_done) if (!e) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     uint32_t spass = p->samples_per_pass;
-    if (spass == 0) rc = ws_ensure_default(sc, lane == 0 ? sc->ws : sc->ws2, npix, p->max_depth, spp, false, spass);   // one lane per job: not halved
+    const bool compact = !(p->integrator == RT_INT_MIS && sc->dev.n_lights > 0);   // as run_paths decides it
+    if (spass == 0) rc = ws_ensure_default(sc, lane == 0 ? sc->ws : sc->ws2, npix, p->max_depth, spp, false, spass, compact);   // one lane per job: not halved
     else {
         spass = std::max(1u, std::min(spass, spp));
         if ((uint64_t)npix * spass > 0x7FFFFF00ull) return fail(RT_ERR_BAD_ARG, "samples_per_pass * pixels too large");
-        rc = ws_ensure(sc, lane == 0 ? sc->ws : sc->ws2, npix * spass, p->max_depth);
+        rc = ws_ensure(sc, lane == 0 ? sc->ws : sc->ws2, npix * spass, p->max_depth, compact);
     }
     if (rc != RT_OK) return rc;
     rt_job* J = new (std::nothrow) rt_job();

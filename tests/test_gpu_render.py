@@ -257,10 +257,10 @@ def test_default_pass_size_steps_down_when_the_gpu_is_occupied(gpu_ctx):
     # rt_stats.samples_per_pass reports it; the frame equals the one an explicit samples_per_pass of that size gives.
     hs = rt.HostScene.builtin("simple_triangle", bvh_seed=3)
     gs = gpu_ctx.upload(hs)
-    w, h, depth, spp = 1920, 1080, 5, 8                            # 1.66 GB of path state per sample of every pixel
+    w, h, depth, spp = 1920, 1080, 5, 8                            # 1.0 GB of path state per sample of every pixel (a scene without lights: 32-byte bounce records)
     torch.cuda.synchronize()
     free = torch.cuda.mem_get_info()[0]
-    hog = torch.empty(free - (4 << 30), dtype=torch.uint8, device="cuda")     # leaves 4 GiB: the default pass (4 spp, 6.6 GB) cannot fit
+    hog = torch.empty(free - (2 << 30), dtype=torch.uint8, device="cuda")     # leaves 2 GiB: the default pass (4 spp, 3.6 GB) cannot fit, 2 spp can
     try:
         a, sa = gs.render_host(w, h, 0, spp, depth, rt.INT_MIS, seed=6)
         assert 1 <= sa.samples_per_pass < 4 and sa.paths == w * h * spp
